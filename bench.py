@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- env steps/s of the tensor-game step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is ONE launch of the hot-path kernel (tg_step_i8, in place) over the whole batch of
+games resident in HBM.  Workload at every N: BASELINE config 2 per GPU -- S=4 int8, 65 536
+independent games per GPU (weak scaling: games are sharded by contiguous global id range, no
+collective on the data path).  The K timed steps are chained (each step consumes the state the
+previous one wrote) and cycle through a 2R-action schedule that returns every game to its start
+state, so the timed region checks itself.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- algorithmic bytes per launch / average launch time (HIP events on the launch
+                  stream) against the 8 TB/s HBM peak, for the kernel the timed region runs;
+  cpu_baseline -- the oracle's reference-dtype torch-CPU port (oracle/ref_dtype_torch.py) timed
+                  on this box's host cores on a bounded sample of the same workload;
+  also         -- the same measurement on the other single-GPU BASELINE configs and on a
+                  batch large enough to stream from HBM (informational, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def bytes_step(S: int) -> int:
+    """read state + read action + write state + write done."""
+    return 2 * S ** 3 + 3 * S + 1
+
+
+def make_schedule(B, S, R, dev, seed, gid0):
+    """Start state + 2R token tensors: the demo's own R actions, then the same actions with u
+    negated (which add the terms back).  After R steps every game is zero; after 2R it is back."""
+    from mat_mul_amd import ops
+
+    actions, target = ops.gen_demos(B, S, R, dev, seed=seed, game_id_offset=gid0)
+    sched = []
+    for k in range(R):
+        sched.append(actions[:, k].contiguous())
+    for k in range(R):
+        a = actions[:, k].clone()
+        a[:, :S] = 2 - a[:, :S]  # token = u + 1  ->  -u + 1
+        sched.append(a.contiguous())
+    return target, sched
+
+
+def time_steps(B, S, K, W, dev, mode, seed=0, gid0=0, R=None, sync=None):
+    """Returns dict(wall_s, event_ms, ok).  EXACTLY K timed launches after W warm-up launches."""
+    from mat_mul_amd import ops
+
+    R = R or (7 if S == 4 else 8)
+    target, sched = make_schedule(B, S, R, dev, seed, gid0)
+    state = ops.alloc_states(B, S, dev)
+    state.copy_(target)
+    done = torch.zeros(B, dtype=torch.uint8, device=dev)
+    ovf = torch.zeros(B, dtype=torch.uint8, device=dev)
+    launch = ops.prepare_step(state, sched, done, ovf, shift=1)
+    L = len(sched)
+    pos = 0
+    for _ in range(W):
+        launch(pos % L)
+        pos += 1
+    torch.cuda.synchronize(dev)
+    start_pos = pos
+
+    graphs = []
+    if mode == "graph":
+        CH = 2048  # kernel nodes per graph
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        k = 0
+        while k < K:
+            n = min(CH, K - k)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for j in range(n):
+                    launch((start_pos + k + j) % L)
+            graphs.append(g)
+            k += n
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        # capture does not execute: the state is still at start_pos
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if sync:
+        sync()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev0.record()
+    if mode == "graph":
+        for g in graphs:
+            g.replay()
+    else:
+        for k in range(K):
+            launch((start_pos + k) % L)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    if sync:
+        sync()
+    wall = time.perf_counter() - t0
+    pos = start_pos + K
+    # self-check of the timed region: finish the current 2R cycle and compare with the start state
+    while pos % L:
+        launch(pos % L)
+        pos += 1
+    torch.cuda.synchronize(dev)
+    ok = bool(torch.equal(state, target)) and not bool(ovf.any())
+    return {"wall_s": wall, "event_ms": ev0.elapsed_time(ev1), "ok": ok}
+
+
+def roofline(B, S, K, event_ms):
+    per_launch_s = event_ms * 1e-3 / K
+    achieved = B * bytes_step(S) / per_launch_s / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "tg::s4_kernel<STEP>" if S == 4 else f"tg::team_kernel<{S},...,STEP>",
+            "bytes_per_launch": B * bytes_step(S), "avg_launch_us": round(per_launch_s * 1e6, 3)}
+
+
+def cpu_baseline(B, S, budget_s=12.0):
+    """The reference-dtype torch-CPU port on this host: fp32 (B,1,S,S,S) state, int64 tokens."""
+    import numpy as np
+    from oracle import ref_dtype_torch as P
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    state = torch.from_numpy(rng.integers(-2, 3, size=(B, 1, S, S, S)).astype(np.float32))
+    acts = torch.from_numpy(rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 1, 3 * S)).astype(np.int64))
+    P.env_step(state, acts)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        state, done = P.env_step(state, acts)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and n >= 5) or n >= 100000:
+            break
+    # per-game loop (how the reference actually calls it: B=1, k=1), bounded sample
+    s1 = torch.zeros((1, 1, S, S, S))
+    a1 = acts[:1]
+    m, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < 2.0:
+        s1, d1 = P.env_step(s1, a1)
+        m += 1
+    single = m / (time.perf_counter() - t1)
+    return {"value": round(B * n / el, 1), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} batched steps of the same workload (B={B}, S={S}; fp32 state, int64 tokens, "
+                      f"torch-CPU op sequence of get_child_states + zero check) in {el:.1f} s",
+            "per_game_loop_steps_per_s": round(single, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2016)
+    ap.add_argument("--warmup", type=int, default=224)
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="graph: the K launches are captured in hipGraphs and replayed; eager: K ctypes launches")
+    ap.add_argument("--dim", type=int, default=4, help="S of the timed workload (4 = BASELINE config 2)")
+    ap.add_argument("--batch", type=int, default=0, help="games per GPU (default: 65536 for S=4, 8192 for S=16)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # control plane only: barrier + max of the elapsed time
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    import mat_mul_amd  # noqa: F401  (raises if libtensorgame.so is missing)
+    from mat_mul_amd import shard_range
+
+    S = args.dim
+    Bg = args.batch or {4: 65536, 16: 8192, 25: 4096, 9: 32768}.get(S, 4096)
+    lo, hi = shard_range(Bg * world, rank, world)  # weak scaling: Bg games per GPU
+    B = hi - lo
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+
+    res = time_steps(B, S, args.steps, args.warmup, dev, args.mode, seed=0, gid0=lo, sync=sync)
+    wall, ok = res["wall_s"], res["ok"]
+    if dist is not None:
+        t = torch.tensor([wall, 0.0 if ok else 1.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ok = float(t[0]), float(t[1]) == 0.0
+    if not ok:
+        raise SystemExit("bench self-check failed: the state did not return to its start after full cycles")
+
+    if rank == 0:
+        total_steps = Bg * world * args.steps
+        out = {
+            "metric": "env steps/sec (batched games)", "value": round(total_steps / wall, 1), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+            "config": {"workload": f"S={S} int8, batch={Bg} independent games per GPU, one in-place tg_step_i8 "
+                                   f"launch per step (BASELINE config {2 if S == 4 else 3})",
+                       "S": S, "batch_per_gpu": Bg, "global_batch": Bg * world, "launch": args.mode,
+                       "parallelism": f"shard{world} (contiguous game ranges, no collective)"},
+            "roofline": roofline(B, S, args.steps, res["event_ms"]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(Bg, S)
+        if world == 1 and not args.no_also:
+            also = []
+            for (s2, b2, k2, label) in [(16, 8192, 504, "BASELINE config 3"), (4, 1 << 22, 112, "HBM-streaming batch (268 MB of states)"),
+                                        (25, 4096, 208, "config 5 per-GPU step"), (16, 1 << 17, 56, "HBM-streaming batch (537 MB of states)")]:
+                if s2 == S and b2 == Bg:
+                    continue
+                r2 = time_steps(b2, s2, k2, 32, dev, args.mode, seed=1)
+                also.append({"workload": f"S={s2} batch={b2} ({label})", "ok": r2["ok"],
+                             "value": round(b2 * k2 / r2["wall_s"], 1), "unit": "steps/s",
+                             "roofline": roofline(b2, s2, k2, r2["event_ms"])})
+            out["also"] = also
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

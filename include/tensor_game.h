@@ -1,0 +1,137 @@
+/*
+ * tensor_game.h -- C ABI of libtensorgame.so: the MI355X (gfx950) tensor-game hot path.
+ *
+ * The reference (kurtosis/mat_mul, pure Python/PyTorch) has no FFI boundary for this path
+ * (SURVEY.md section 8b): the path is reached by direct Python calls on torch tensors.  Each entry
+ * point below therefore names the reference *function* it replaces (file:line in /root/reference).
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer (HIP, gfx950) unless the
+ *     parameter is documented "host";
+ *   - asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*, NULL = the
+ *     null stream); the caller synchronises.  No allocation, no host sync, no global mutable
+ *     state inside a call -- every call may be captured into a hipGraph;
+ *   - return 0 on success, a negative TG_ERR_* otherwise; tg_last_error() returns a thread-local
+ *     message for the last failing call on this thread.  No exception crosses the boundary;
+ *   - states are int8, C-contiguous (S,S,S) per game, game b at `base + b*game_stride_bytes`
+ *     (game_stride_bytes >= S*S*S).  Any alignment is accepted; base and stride multiples of 16
+ *     take the fast path.  Element [i][j][l] of an action tensor is u_i*v_j*w_l.
+ *   - actions are int8 tokens, C-contiguous (...,3*S) = cat(u,v,w)+shift (reference utils.py:56-66);
+ *     factor value = token - shift, computed in 32-bit.
+ *   - the reference computes in float32 and can never overflow; here every result is computed in
+ *     32-bit, narrowed to int8 with two's-complement wrap, and `overflow` (uint8 per game, may be
+ *     NULL) is SET to 1 when any entry left [-128,127].  It is sticky: calls never clear it.
+ *   - in-place operation (state_out == state_in) is allowed wherever both appear.
+ *   - supported sizes: 1 <= S <= TG_MAX_S.
+ */
+#ifndef TENSOR_GAME_H_
+#define TENSOR_GAME_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_ABI_VERSION 1
+#define TG_MAX_S 32
+#define TG_MAX_VALUES 8 /* categories of the factor distribution */
+
+enum {
+  TG_OK = 0,
+  TG_ERR_INVALID = -1,     /* null pointer, size out of range, stride < S^3, misaligned actions ... */
+  TG_ERR_UNSUPPORTED = -2, /* valid request this build does not implement */
+  TG_ERR_HIP = -3          /* HIP runtime error (message holds hipGetErrorString) */
+};
+
+typedef void* tg_stream_t; /* hipStream_t */
+
+int tg_abi_version(void);
+const char* tg_last_error(void);
+
+/* ---- the env step ------------------------------------------------------------------------- */
+
+/* state_out[b] = state_in[b] - u(x)v(x)w of actions[b];  done[b] = (state_out[b] == 0 everywhere).
+ * Replaces get_child_states (act.py:266-275) for k=1,T=1 + tensor_factorized on each game's head
+ * (utils.py:181-188 as called at act.py:177).  actions: int8 (B,3S).  done: uint8 (B). */
+int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions, uint8_t* done,
+               uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes, int shift,
+               tg_stream_t stream);
+
+/* K sequential steps with the state resident on chip.  actions: int8 (B,K,3S).
+ * done_step[b] (int32) = first step index whose post-state is all zero, or -1.
+ * Replaces SyntheticDemoDataset._take_actions (datasets.py:144-153) / K calls of tg_step_i8. */
+int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
+                    int32_t* done_step, uint8_t* overflow, int64_t B, int S, int K,
+                    int64_t game_stride_bytes, int shift, tg_stream_t stream);
+
+/* k children per parent: state_out[b*k+i] = state_in[b] - tensor(actions[b][i]).
+ * done, changed, overflow: uint8 (B,k); changed[b][i] = child differs from parent (the per-game
+ * form of remove_null_actions, utils.py:191-194); changed/overflow may be NULL.
+ * Replaces get_child_states (act.py:266-275) with k>1, T=1. */
+int tg_expand_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions, uint8_t* done,
+                 uint8_t* changed, uint8_t* overflow, int64_t B, int S, int k,
+                 int64_t in_stride_bytes, int64_t out_stride_bytes, int shift, tg_stream_t stream);
+
+/* done[b] = (state[b] == 0 everywhere); nnz[b] (int32, may be NULL) = number of non-zero entries.
+ * Replaces tensor_factorized (utils.py:181-188) per game and the nnz bound of training.py:266. */
+int tg_done_i8(const int8_t* state, uint8_t* done, int32_t* nnz, int64_t B, int S,
+               int64_t game_stride_bytes, tg_stream_t stream);
+
+/* ---- reset -------------------------------------------------------------------------------- */
+
+/* every game <- the <n,n,n> matrix-multiplication tensor, S = n*n.
+ * Replaces build_matmul_tensor(dim_t,n,n,n)[0] (utils.py:143-161). */
+int tg_reset_matmul_i8(int8_t* state_out, int64_t B, int n, int64_t game_stride_bytes,
+                       tg_stream_t stream);
+
+/* every game <- the S^3-byte template `start` (device pointer): the synthetic start tensor of
+ * training.py:363-392 / a caller-supplied start_tensor (datasets.py:278-280). */
+int tg_reset_broadcast_i8(const int8_t* start, int8_t* state_out, int64_t B, int S,
+                          int64_t game_stride_bytes, tg_stream_t stream);
+
+/* ---- synthetic-demonstration generator ---------------------------------------------------- */
+
+/* target_out[b] = sum_r tensor(actions[b][r]); actions: int8 (B,R,3S).  The deterministic half of
+ * create_synthetic_demo (utils.py:218-232; datasets.py:127-141) and uvw_to_demo (utils.py:40-53):
+ * the bit-exact parity hook against reference-drawn factors. */
+int tg_gen_from_factors_i8(const int8_t* actions, int8_t* target_out, uint8_t* overflow,
+                           int64_t B, int S, int R, int64_t game_stride_bytes, int shift,
+                           tg_stream_t stream);
+
+/* The generator: for game id g = game_id_offset + b, for each of R terms, each of u,v,w is redrawn
+ * until it is not the zero vector; tokens = cat(u,v,w)+shift -> actions_out int8 (B,R,3S);
+ * target_out[b] = sum of the R rank-1 terms.  Replaces create_synthetic_demo (utils.py:203-233) /
+ * SyntheticDemoDataset._create_synthetic_demos (datasets.py:124-142) + _factor_sample (:155-158).
+ * RNG: Philox-4x32-10, key = seed, counter = (g_lo, g_hi, 3*r+x, attempt<<8 | block) -- keyed by
+ * the GLOBAL game id, so output does not depend on how games are sharded over GPUs.
+ * values: host int8[n_values]; thresholds: host uint32[n_values-1], ascending cdf * 2^32:
+ * a 32-bit draw d selects values[#{t : d >= t}].
+ * basis (may be NULL): int8 (B,3,S,S) per-game matrices (A,B,C); when given, every term is
+ * emitted in the new basis: (u,v,w) -> (Au,Bv,Cw) (not in the reference). */
+int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, int64_t B, int S,
+                    int R, const uint32_t* thresholds, const int8_t* values, int n_values,
+                    int shift, uint64_t seed, uint64_t game_id_offset, const int8_t* basis,
+                    int64_t game_stride_bytes, tg_stream_t stream);
+
+/* ---- change of basis (from the AlphaTensor paper, NOT in the reference) ---- */
+
+/* basis_out int8 (B,3,S,S): P = L*U, L/U unit(+-1)-diagonal lower/upper triangular with
+ * off-diagonal entries drawn like factor values; det P = +-1.  lower_out/upper_out (may be NULL)
+ * receive L and U.  Counter = (g_lo, g_hi, 0x80000000|mode, cell/4). */
+int tg_sample_basis_i8(int8_t* basis_out, int8_t* lower_out, int8_t* upper_out, int64_t B, int S,
+                       const uint32_t* thresholds, const int8_t* values, int n_values,
+                       uint64_t seed, uint64_t game_id_offset, tg_stream_t stream);
+
+/* state_out[b][a][c][d] = sum_ijk A[a][i] B[c][j] C[d][k] state_in[b][i][j][k],
+ * basis int32 (B,3,S,S) (int32 so that exact inverses of unimodular matrices fit). */
+int tg_change_basis_i8(const int8_t* state_in, const int32_t* basis, int8_t* state_out,
+                       uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes,
+                       tg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TENSOR_GAME_H_ */

@@ -1,0 +1,69 @@
+"""ctypes binding of include/tensor_game.h.  The product has NO fallback: if the HIP
+library is missing or an entry point is absent, importing this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libtensorgame.so"
+
+TG_ABI_VERSION = 1
+TG_MAX_S = 32
+TG_MAX_VALUES = 8
+TG_MAX_ACTIONS = 4096
+
+
+class TensorGameError(RuntimeError):
+    """A tg_* entry point returned a negative code; the message is tg_last_error()."""
+
+    def __init__(self, fn: str, code: int, msg: str):
+        super().__init__(f"{fn} failed ({code}): {msg}")
+        self.code = code
+
+
+_p, _i, _i64, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
+
+# name -> argtypes; every symbol include/tensor_game.h declares
+SIGNATURES = {
+    "tg_abi_version": [],
+    "tg_last_error": [],
+    "tg_step_i8": [_p, _p, _p, _p, _p, _i64, _i, _i64, _i, _p],
+    "tg_step_many_i8": [_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _p],
+    "tg_expand_i8": [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i, _p],
+    "tg_done_i8": [_p, _p, _p, _i64, _i, _i64, _p],
+    "tg_reset_matmul_i8": [_p, _i64, _i, _i64, _p],
+    "tg_reset_broadcast_i8": [_p, _p, _i64, _i, _i64, _p],
+    "tg_gen_from_factors_i8": [_p, _p, _p, _i64, _i, _i, _i64, _i, _p],
+    "tg_gen_demos_i8": [_p, _p, _p, _i64, _i, _i, _p, _p, _i, _i, _u64, _u64, _p, _i64, _p],
+    "tg_sample_basis_i8": [_p, _p, _p, _i64, _i, _p, _p, _i, _u64, _u64, _p],
+    "tg_change_basis_i8": [_p, _p, _p, _p, _i64, _i, _i64, _p],
+}
+
+
+def _load() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP library is not built.  Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `python -m mat_mul_amd.build`). "
+            "mat_mul_amd has no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "tg_last_error" else C.c_int
+    if lib.tg_abi_version() != TG_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.tg_abi_version()} != {TG_ABI_VERSION}; rebuild it")
+    return lib
+
+
+lib = _load()
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise TensorGameError(name, rc, lib.tg_last_error().decode("utf-8", "replace"))

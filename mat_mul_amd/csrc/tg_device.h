@@ -1,0 +1,60 @@
+// Device-side helpers shared by the tensor-game kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tg {
+
+constexpr int kBlock = 256;  // 4 wavefronts of 64
+
+// ---- packed int8 <-> int32 ------------------------------------------------------------------
+
+// sign-extended byte t (0..3) of a dword: one v_bfe_i32
+__device__ __forceinline__ int sbyte(uint32_t w, int t) {
+  return __builtin_amdgcn_sbfe(static_cast<int>(w), 8 * t, 8);
+}
+
+// low bytes of four ints -> one dword (3 x v_perm_b32)
+__device__ __forceinline__ uint32_t pack4(int n0, int n1, int n2, int n3) {
+  uint32_t lo = __builtin_amdgcn_perm(static_cast<uint32_t>(n1), static_cast<uint32_t>(n0), 0x0c0c0400u);
+  uint32_t hi = __builtin_amdgcn_perm(static_cast<uint32_t>(n3), static_cast<uint32_t>(n2), 0x0c0c0400u);
+  return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+// a*b + c with |a|,|b| < 2^23: one v_mad_i32_i24 (full-rate, unlike v_mul_lo_u32)
+__device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+
+// ---- team (sub-wave) reductions --------------------------------------------------------------
+
+// OR-reduce a predicate over the TS consecutive lanes (TS a power of two <= 64) this lane belongs to.
+template <int TS>
+__device__ __forceinline__ bool team_any(bool p) {
+  const uint64_t m = __ballot(p);
+  if constexpr (TS >= 64) {
+    return m != 0;
+  } else {
+    const int lane = threadIdx.x & 63;
+    const int base = lane & ~(TS - 1);
+    return ((m >> base) & ((1ull << TS) - 1ull)) != 0;
+  }
+}
+
+// ---- Philox-4x32-10 (Salmon et al. SC'11); bit-identical to oracle/tensor_game.py -----------
+
+struct U4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+}  // namespace tg

@@ -1,0 +1,293 @@
+// Generator side of libtensorgame.so: counter-based RNG -> factor tokens, random unimodular
+// bases, and the change of basis (three mode products).  gfx950 only.
+//
+// The generator is split in two kernels: gen_tokens_kernel draws the factor vectors (Philox,
+// per-vector rejection of the zero vector, optional change of basis on the factors) and writes
+// the int8 tokens; the rank-1 accumulation then runs in the GENF kernels of tg_kernels.hip on
+// those tokens (tg_gen_from_factors_i8).  The target is therefore always exactly the sum of the
+// rank-1 terms of the EMITTED tokens.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "../../include/tensor_game.h"
+#include "tg_device.h"
+
+int tg_internal_fail(int code, const char* fmt, ...);  // tg_kernels.hip
+
+namespace tg {
+
+struct Dist {
+  uint32_t thr[TG_MAX_VALUES - 1];
+  int8_t val[TG_MAX_VALUES];
+  int nv;
+};
+
+__device__ __forceinline__ int draw_value(uint32_t d, const Dist& D) {
+  int idx = 0;
+#pragma unroll
+  for (int t = 0; t < TG_MAX_VALUES - 1; ++t) idx += (t < D.nv - 1) && (d >= D.thr[t]);
+  int v = D.val[0];
+#pragma unroll
+  for (int t = 1; t < TG_MAX_VALUES; ++t) v = (idx == t) ? D.val[t] : v;
+  return v;
+}
+
+constexpr uint32_t kStreamBasis = 0x80000000u;
+constexpr uint32_t kMaxAttempts = 1u << 16;
+
+// One thread per factor vector (game b, term r, x in {u,v,w}).  Counter = (gid_lo, gid_hi,
+// 3r+x, attempt<<8 | block), key = seed: identical to oracle/tensor_game.py::_draw_vector.
+__global__ __launch_bounds__(kBlock) void gen_tokens_kernel(int8_t* actions_out, uint8_t* overflow, int64_t B,
+                                                            int S, int R, Dist D, int shift, uint64_t seed,
+                                                            uint64_t gid0, const int8_t* basis) {
+  const int64_t nvec = B * R * 3;
+  const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < nvec;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t b = idx / (3 * R);
+    const int sub = static_cast<int>(idx - b * 3 * R);  // 3r + x
+    const int x = sub % 3;
+    const uint64_t gid = gid0 + static_cast<uint64_t>(b);
+    int f[TG_MAX_S];
+    const int nblk = (S + 3) >> 2;
+    for (uint32_t attempt = 0;; ++attempt) {
+      bool any = false;
+      for (int q = 0; q < nblk; ++q) {
+        const U4 o = philox4x32_10(U4{static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
+                                      static_cast<uint32_t>(sub), (attempt << 8) | static_cast<uint32_t>(q)},
+                                   k0, k1);
+        const uint32_t d[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int s = 4 * q + t;
+          if (s < S) {
+            f[s] = draw_value(d[t], D);
+            any |= f[s] != 0;
+          }
+        }
+      }
+      if (any || attempt + 1 >= kMaxAttempts) break;
+    }
+    int8_t* dst = actions_out + idx * S;  // ((b*R + r)*3 + x)*S
+    int bad = 0;
+    if (basis) {
+      const int8_t* M = basis + (b * 3 + x) * S * S;
+      for (int a = 0; a < S; ++a) {
+        int acc = 0;
+        for (int i = 0; i < S; ++i) acc += M[a * S + i] * f[i];
+        const int tokv = acc + shift;
+        bad |= tokv + 128;
+        dst[a] = static_cast<int8_t>(tokv);
+      }
+    } else {
+      for (int s = 0; s < S; ++s) {
+        const int tokv = f[s] + shift;
+        bad |= tokv + 128;
+        dst[s] = static_cast<int8_t>(tokv);
+      }
+    }
+    if (overflow && (bad & ~255)) overflow[b] = 1;
+  }
+}
+
+// One workgroup per (game, mode): L and U cells from one draw each, then P = L @ U.
+__global__ __launch_bounds__(kBlock) void sample_basis_kernel(int8_t* P, int8_t* Lo, int8_t* Uo, int64_t B, int S,
+                                                              Dist D, uint64_t seed, uint64_t gid0) {
+  __shared__ int8_t L[TG_MAX_S * TG_MAX_S], U[TG_MAX_S * TG_MAX_S];
+  const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+  const int cells = S * S, nblk = (cells + 3) >> 2;
+  for (int64_t m = blockIdx.x; m < 3 * B; m += gridDim.x) {
+    const int64_t b = m / 3;
+    const int x = static_cast<int>(m - 3 * b);
+    const uint64_t gid = gid0 + static_cast<uint64_t>(b);
+    for (int q = threadIdx.x; q < nblk; q += kBlock) {
+      const U4 o = philox4x32_10(U4{static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
+                                    kStreamBasis | static_cast<uint32_t>(x), static_cast<uint32_t>(q)},
+                                 k0, k1);
+      const uint32_t d[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 4 * q + t;
+        if (c < cells) {
+          const int a = c / S, bb = c - a * S;
+          const int v = draw_value(d[t], D);
+          L[c] = a > bb ? v : (a == bb ? 1 - 2 * static_cast<int>(d[t] & 1u) : 0);
+          U[c] = a < bb ? v : (a == bb ? 1 - 2 * static_cast<int>((d[t] >> 1) & 1u) : 0);
+        }
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cells; c += kBlock) {
+      const int a = c / S, bb = c - a * S;
+      int acc = 0;
+      const int kmax = a < bb ? a : bb;
+      for (int k = 0; k <= kmax; ++k) acc += L[a * S + k] * U[k * S + bb];
+      P[m * cells + c] = static_cast<int8_t>(acc);  // |acc| <= S <= 32
+      if (Lo) Lo[m * cells + c] = L[c];
+      if (Uo) Uo[m * cells + c] = U[c];
+    }
+    __syncthreads();
+  }
+}
+
+// Change of basis: one workgroup per game, the S^3 int32 tensor lives in LDS ([i][j][k] with the
+// k-rows padded to S+1 so that all three fibre directions are bank-conflict free) and is
+// transformed IN PLACE one mode at a time; each thread owns whole fibres.
+template <int ST>
+__global__ __launch_bounds__(kBlock) void change_basis_kernel(const int8_t* in, const int32_t* basis, int8_t* out,
+                                                              uint8_t* overflow, int64_t B, int Srt, int64_t stride) {
+  extern __shared__ int X[];
+  const int S = ST ? ST : Srt;
+  const int P = S + 1, S2 = S * S, N = S2 * S;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const int8_t* src = in + b * stride;
+    for (int e = threadIdx.x; e < N; e += kBlock) {
+      const int i = e / S2, r = e - i * S2, j = r / S, k = r - j * S;
+      X[(i * S + j) * P + k] = src[e];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int mode = 0; mode < 3; ++mode) {
+      const int32_t* M = basis + (b * 3 + mode) * S2;
+      // element (f, t) of a fibre: mode 0 walks i, mode 1 walks j, mode 2 walks k
+      const int step = mode == 0 ? S * P : (mode == 1 ? P : 1);
+      for (int f = threadIdx.x; f < S2; f += kBlock) {
+        const int p = f / S, q = f - p * S;
+        const int base = mode == 0 ? p * P + q : (mode == 1 ? p * S * P + q : (p * S + q) * P);
+        int x[ST ? ST : TG_MAX_S];
+#pragma unroll
+        for (int t = 0; t < (ST ? ST : TG_MAX_S); ++t)
+          if (t < S) x[t] = X[base + t * step];
+        for (int a = 0; a < S; ++a) {
+          int acc = 0;
+#pragma unroll
+          for (int t = 0; t < (ST ? ST : TG_MAX_S); ++t)
+            if (t < S) acc += M[a * S + t] * x[t];
+          X[base + a * step] = acc;
+        }
+      }
+      __syncthreads();
+    }
+    int8_t* dst = out + b * stride;
+    int ovf = 0;
+    for (int e = threadIdx.x; e < N; e += kBlock) {
+      const int i = e / S2, r = e - i * S2, j = r / S, k = r - j * S;
+      const int v = X[(i * S + j) * P + k];
+      ovf |= (v < -128) | (v > 127);
+      dst[e] = static_cast<int8_t>(v);
+    }
+    ovf = __syncthreads_or(ovf);
+    if (threadIdx.x == 0 && overflow && ovf) overflow[b] = 1;
+  }
+}
+
+}  // namespace tg
+
+namespace {
+
+int make_dist(const char* fn, const uint32_t* thresholds, const int8_t* values, int nv, tg::Dist* D) {
+  if (!thresholds || !values) return tg_internal_fail(TG_ERR_INVALID, "%s: null distribution", fn);
+  if (nv < 1 || nv > TG_MAX_VALUES)
+    return tg_internal_fail(TG_ERR_INVALID, "%s: n_values=%d outside [1,%d]", fn, nv, TG_MAX_VALUES);
+  bool nonzero = false;
+  for (int t = 0; t < TG_MAX_VALUES; ++t) D->val[t] = t < nv ? values[t] : 0;
+  for (int t = 0; t < TG_MAX_VALUES - 1; ++t) D->thr[t] = t < nv - 1 ? thresholds[t] : 0xffffffffu;
+  for (int t = 0; t + 2 < nv; ++t)
+    if (thresholds[t] > thresholds[t + 1])
+      return tg_internal_fail(TG_ERR_INVALID, "%s: thresholds must be ascending", fn);
+  for (int t = 0; t < nv; ++t) {
+    const uint64_t lo = t == 0 ? 0 : thresholds[t - 1];
+    const uint64_t hi = t == nv - 1 ? (1ull << 32) : thresholds[t];
+    if (values[t] != 0 && hi > lo) nonzero = true;
+  }
+  if (!nonzero) return tg_internal_fail(TG_ERR_INVALID, "%s: distribution never draws a non-zero value", fn);
+  D->nv = nv;
+  return TG_OK;
+}
+
+int launched(const char* fn) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tg_internal_fail(TG_ERR_HIP, "%s: %s", fn, hipGetErrorString(e));
+  return TG_OK;
+}
+
+unsigned grid_for(int64_t blocks) {
+  const int64_t cap = 1 << 20;
+  return static_cast<unsigned>(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, int64_t B, int S,
+                    int R, const uint32_t* thresholds, const int8_t* values, int n_values,
+                    int shift, uint64_t seed, uint64_t game_id_offset, const int8_t* basis,
+                    int64_t game_stride_bytes, tg_stream_t stream) {
+  const char* fn = "tg_gen_demos_i8";
+  if (B < 0 || S < 1 || S > TG_MAX_S || game_stride_bytes < (int64_t)S * S * S)
+    return tg_internal_fail(TG_ERR_INVALID, "%s: bad B/S/stride", fn);
+  if (R < 1 || R > 4096) return tg_internal_fail(TG_ERR_INVALID, "%s: R=%d outside [1,4096]", fn, R);
+  tg::Dist D;
+  if (int rc = make_dist(fn, thresholds, values, n_values, &D)) return rc;
+  if (B == 0) return TG_OK;
+  if (!target_out || !actions_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  const int64_t nvec = B * R * 3;
+  hipLaunchKernelGGL(tg::gen_tokens_kernel, dim3(grid_for((nvec + tg::kBlock - 1) / tg::kBlock)),
+                     dim3(tg::kBlock), 0, static_cast<hipStream_t>(stream), actions_out, overflow, B, S, R,
+                     D, shift, seed, game_id_offset, basis);
+  if (int rc = launched(fn)) return rc;
+  return tg_gen_from_factors_i8(actions_out, target_out, overflow, B, S, R, game_stride_bytes, shift, stream);
+}
+
+int tg_sample_basis_i8(int8_t* basis_out, int8_t* lower_out, int8_t* upper_out, int64_t B, int S,
+                       const uint32_t* thresholds, const int8_t* values, int n_values,
+                       uint64_t seed, uint64_t game_id_offset, tg_stream_t stream) {
+  const char* fn = "tg_sample_basis_i8";
+  if (B < 0 || S < 1 || S > TG_MAX_S) return tg_internal_fail(TG_ERR_INVALID, "%s: bad B/S", fn);
+  tg::Dist D;
+  if (int rc = make_dist(fn, thresholds, values, n_values, &D)) return rc;
+  if (B == 0) return TG_OK;
+  if (!basis_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  hipLaunchKernelGGL(tg::sample_basis_kernel, dim3(grid_for(3 * B)), dim3(tg::kBlock), 0,
+                     static_cast<hipStream_t>(stream), basis_out, lower_out, upper_out, B, S, D, seed,
+                     game_id_offset);
+  return launched(fn);
+}
+
+int tg_change_basis_i8(const int8_t* state_in, const int32_t* basis, int8_t* state_out,
+                       uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes,
+                       tg_stream_t stream) {
+  const char* fn = "tg_change_basis_i8";
+  if (B < 0 || S < 1 || S > TG_MAX_S || game_stride_bytes < (int64_t)S * S * S)
+    return tg_internal_fail(TG_ERR_INVALID, "%s: bad B/S/stride", fn);
+  if (B == 0) return TG_OK;
+  if (!state_in || !basis || !state_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  if (state_in == state_out) return tg_internal_fail(TG_ERR_INVALID, "%s: in-place is not supported", fn);
+  const size_t lds = static_cast<size_t>(S) * S * (S + 1) * sizeof(int);
+  if (lds > 160 * 1024) return tg_internal_fail(TG_ERR_UNSUPPORTED, "%s: S=%d needs %zu B of LDS", fn, S, lds);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(B)), block(tg::kBlock);
+#define TG_CB(ST)                                                                                      \
+  do {                                                                                                 \
+    if (lds > 64 * 1024) {                                                                             \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tg::change_basis_kernel<ST>),   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+      if (e != hipSuccess) return tg_internal_fail(TG_ERR_HIP, "%s: %s", fn, hipGetErrorString(e));    \
+    }                                                                                                  \
+    hipLaunchKernelGGL(tg::change_basis_kernel<ST>, grid, block, lds, st, state_in, basis, state_out,  \
+                       overflow, B, S, game_stride_bytes);                                             \
+  } while (0)
+  switch (S) {
+    case 4: TG_CB(4); break;
+    case 9: TG_CB(9); break;
+    case 16: TG_CB(16); break;
+    case 25: TG_CB(25); break;
+    default: TG_CB(0); break;
+  }
+#undef TG_CB
+  return launched(fn);
+}
+
+}  // extern "C"

@@ -1,0 +1,728 @@
+// libtensorgame.so -- hand-written gfx950 (MI355X, CDNA4) kernels for the tensor-game hot path
+// and the C ABI of include/tensor_game.h.  No MFMA anywhere: the path is HBM-bound byte work
+// (state <- state - u(x)v(x)w, zero check, rank-1 accumulation), see DESIGN.md.
+//
+// Kernel families
+//   slow_*   : one 256-thread workgroup per game, byte-granular.  Any S <= TG_MAX_S, any alignment.
+//   team_*   : aligned layouts (base, stride multiples of 16 B).  A "team" of TS consecutive lanes
+//              owns one game; each lane streams 16-byte chunks (global_load/store_dwordx4), the
+//              factor tokens of the team's games are staged in LDS, the zero check is a wavefront
+//              ballot (TS <= 64) or a workgroup OR (TS = 256).  Instantiated for S = 4, 9, 16, 25.
+//   s4_*     : S = 4 in registers only: 4 lanes per game (16 games per wavefront), one dwordx4
+//              per lane, tokens as three dwords per lane, ballot nibble for the zero check.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/tensor_game.h"
+#include "tg_device.h"
+
+namespace tg {
+
+#define TG_MAX_ACTIONS 4096  // K / k / R per call
+
+enum Mode { STEP = 0, MANY = 1, EXPAND = 2, GENF = 3 };
+
+struct ApplyArgs {
+  const int8_t* in;      // GENF: unused (state starts at zero)
+  int8_t* out;
+  const int8_t* actions; // (B, nact, 3S)
+  uint8_t* done;         // STEP (B) / EXPAND (B,nact)
+  int32_t* done_step;    // MANY (B)
+  uint8_t* changed;      // EXPAND (B,nact), nullable
+  uint8_t* overflow;     // (B) or EXPAND (B,nact), nullable
+  int64_t B;
+  int64_t in_stride;
+  int64_t out_stride;
+  int S;
+  int nact;
+  int shift;
+};
+
+// =============================================================================================
+// slow path: any S, any alignment.  One workgroup per game, one byte per thread-iteration.
+// =============================================================================================
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void slow_kernel(ApplyArgs a) {
+  __shared__ uint8_t nzf[TG_MAX_ACTIONS];
+  const int S = a.S, S2 = S * S, N = S2 * S, A3 = 3 * S;
+  const int tid = threadIdx.x;
+  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const int8_t* tok = a.actions + b * a.nact * A3;
+    if constexpr (MODE == EXPAND) {
+      const int8_t* src = a.in + b * a.in_stride;
+      for (int c = 0; c < a.nact; ++c) {
+        const int8_t* t = tok + c * A3;
+        int8_t* dst = a.out + (b * a.nact + c) * a.out_stride;
+        int nz = 0, chg = 0, ovf = 0;
+        for (int e = tid; e < N; e += kBlock) {
+          const int i = e / S2, r = e - i * S2, j = r / S, l = r - j * S;
+          const int p = (t[i] - a.shift) * (t[S + j] - a.shift) * (t[2 * S + l] - a.shift);
+          const int n = src[e] - p;
+          dst[e] = static_cast<int8_t>(n);
+          nz |= n & 255;
+          chg |= p;
+          ovf |= (n + 128);
+        }
+        nz = __syncthreads_or(nz);
+        chg = __syncthreads_or(chg);
+        ovf = __syncthreads_or(ovf & ~255);
+        if (tid == 0) {
+          a.done[b * a.nact + c] = nz ? 0 : 1;
+          if (a.changed) a.changed[b * a.nact + c] = chg ? 1 : 0;
+          if (a.overflow && ovf) a.overflow[b * a.nact + c] = 1;
+        }
+      }
+    } else {
+      if constexpr (MODE == MANY) {
+        for (int k = tid; k < a.nact; k += kBlock) nzf[k] = 0;
+        __syncthreads();
+      }
+      const int8_t* src = (MODE == GENF) ? nullptr : a.in + b * a.in_stride;
+      int8_t* dst = a.out + b * a.out_stride;
+      int nz = 0, ovf = 0;
+      for (int e = tid; e < N; e += kBlock) {
+        const int i = e / S2, r = e - i * S2, j = r / S, l = r - j * S;
+        int acc = (MODE == GENF) ? 0 : src[e];
+        for (int k = 0; k < a.nact; ++k) {
+          const int8_t* t = tok + k * A3;
+          const int p = (t[i] - a.shift) * (t[S + j] - a.shift) * (t[2 * S + l] - a.shift);
+          if constexpr (MODE == GENF) {
+            acc += p;
+          } else {
+            acc -= p;
+            ovf |= (acc + 128);
+            if constexpr (MODE == MANY) {
+              if (acc & 255) nzf[k] = 1;
+            }
+          }
+        }
+        if constexpr (MODE == GENF) ovf |= (acc + 128);
+        dst[e] = static_cast<int8_t>(acc);
+        nz |= acc & 255;
+      }
+      nz = __syncthreads_or(nz);
+      ovf = __syncthreads_or(ovf & ~255);
+      if (tid == 0) {
+        if constexpr (MODE == STEP) a.done[b] = nz ? 0 : 1;
+        if constexpr (MODE == MANY) {
+          int first = -1;
+          for (int k = 0; k < a.nact; ++k)
+            if (!nzf[k]) { first = k; break; }
+          a.done_step[b] = first;
+        }
+        if (a.overflow && ovf) a.overflow[b] = 1;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// =============================================================================================
+// team path: aligned layouts, 16-byte chunks, factor tokens staged in LDS.
+// =============================================================================================
+template <int S, int TS>
+struct Geo {
+  static constexpr int N = S * S * S;
+  static constexpr int NCHUNK = (N + 15) / 16;        // chunk c = bytes [16c, 16c+16) of the game
+  static constexpr int NCH = (NCHUNK + TS - 1) / TS;  // chunks per lane
+  static constexpr int GPB = kBlock / TS;             // games per workgroup
+  static constexpr int TAIL = N % 16;                 // valid bytes of the last chunk (0 = full)
+  static constexpr int FSTRIDE = 3 * S + 1;           // LDS shorts per action: v[S] w[S] u[S] 0
+  static constexpr int ATILE_RAW = 32768 / (GPB * FSTRIDE * 2);
+  static constexpr int ATILE = ATILE_RAW > 128 ? 128 : ATILE_RAW;  // actions staged per LDS tile
+  static constexpr int LDS_BYTES = GPB * ATILE * FSTRIDE * 2;
+  static_assert(TS == 4 || TS == 8 || TS == 16 || TS == 32 || TS == 64 || TS == 256, "team size");
+  static_assert(ATILE >= 1, "LDS tile");
+};
+
+// acc[t] += sgn * u_i v_j w_l for the 16 consecutive elements starting at cursor (i,j,l).
+// F (LDS): v at [0,S), w at [S,2S), u at [2S,3S), and a ZERO at [3S]: a cursor that runs past the
+// last element of the game reads u = 0, so the padding lanes of a tail chunk accumulate nothing.
+template <int S, bool SUB>
+__device__ __forceinline__ void rank1_16(int (&acc)[16], int i, int j, int l, const short* F, int& chg) {
+  int ui = F[2 * S + i];
+  if constexpr (SUB) ui = -ui;
+  int uv = __mul24(ui, F[j]);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int p = __mul24(uv, F[S + l]);
+    acc[t] += p;
+    chg |= p;
+    if (++l == S) {
+      l = 0;
+      if (++j == S) {
+        j = 0;
+        ++i;
+        ui = F[2 * S + i];
+        if constexpr (SUB) ui = -ui;
+      }
+      uv = __mul24(ui, F[j]);
+    }
+  }
+}
+
+__device__ __forceinline__ void unpack16(const uint4& q, int (&acc)[16]) {
+  const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[4 * d + t] = sbyte(w[d], t);
+}
+
+// narrow with wrap; nz |= any non-zero output byte; ovf |= bits >= 8 of (n+128) when out of range
+__device__ __forceinline__ uint4 pack16(const int (&acc)[16], uint32_t& nz, int& ovf) {
+  uint32_t w[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ovf |= acc[4 * d + t] + 128;
+    w[d] = pack4(acc[4 * d], acc[4 * d + 1], acc[4 * d + 2], acc[4 * d + 3]);
+    nz |= w[d];
+  }
+  return uint4{w[0], w[1], w[2], w[3]};
+}
+
+template <int TAIL>
+__device__ __forceinline__ uint4 load_chunk(const int8_t* p, bool tail) {
+  if (TAIL != 0 && tail) {  // last chunk of the game: only TAIL bytes belong to it
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < TAIL; ++t) w[t >> 2] |= static_cast<uint32_t>(static_cast<uint8_t>(p[t])) << (8 * (t & 3));
+    return uint4{w[0], w[1], w[2], w[3]};
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
+
+template <int TAIL>
+__device__ __forceinline__ void store_chunk(int8_t* p, const uint4& q, bool tail) {
+  if (TAIL != 0 && tail) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int t = 0; t < TAIL; ++t) p[t] = static_cast<int8_t>(w[t >> 2] >> (8 * (t & 3)));
+    return;
+  }
+  *reinterpret_cast<uint4*>(p) = q;
+}
+
+template <int S, int TS, int MODE>
+__global__ __launch_bounds__(kBlock) void team_kernel(ApplyArgs a) {
+  using G = Geo<S, TS>;
+  constexpr bool SUB = (MODE != GENF);
+  __shared__ short lds[G::LDS_BYTES / 2];
+  __shared__ uint8_t nzf[(MODE == MANY && TS == 256) ? TG_MAX_ACTIONS : 4];
+
+  const int tid = threadIdx.x;
+  const int team = tid / TS, lt = tid % TS;
+  int64_t g = static_cast<int64_t>(blockIdx.x) * G::GPB + team;
+  const bool live = g < a.B;
+  if (!live) g = a.B - 1;  // dead teams shadow the last game (uniform barriers), stores predicated off
+  short* const F = lds + team * (G::ATILE * G::FSTRIDE);
+  const int8_t* const tok = a.actions + g * a.nact * (3 * S);
+
+  // chunk ownership and element cursors: chunk c = n*TS + lt covers elements [16c, 16c+16)
+  int ci[G::NCH], cj[G::NCH], cl[G::NCH];
+  bool cv[G::NCH], ctail[G::NCH];
+#pragma unroll
+  for (int n = 0; n < G::NCH; ++n) {
+    const int c = n * TS + lt;
+    cv[n] = c < G::NCHUNK;
+    ctail[n] = (G::TAIL != 0) && (c == G::NCHUNK - 1);
+    const int e0 = 16 * c;
+    ci[n] = e0 / (S * S);
+    const int r = e0 - ci[n] * (S * S);
+    cj[n] = r / S;
+    cl[n] = r - cj[n] * S;
+  }
+
+  // parent / current state chunks
+  uint4 pk[G::NCH];
+#pragma unroll
+  for (int n = 0; n < G::NCH; ++n) {
+    pk[n] = uint4{0, 0, 0, 0};
+    if (MODE != GENF && cv[n]) pk[n] = load_chunk<G::TAIL>(a.in + g * a.in_stride + 16 * (n * TS + lt), ctail[n]);
+  }
+
+  auto stage = [&](int a0, int na) {  // tokens of actions [a0, a0+na) of this team's game -> LDS
+    __syncthreads();
+    for (int r = lt; r < na * 3 * S; r += TS) {
+      const int k = r / (3 * S), pos = r - k * (3 * S);
+      const int val = tok[(a0 + k) * (3 * S) + pos] - a.shift;
+      // token order is u,v,w; LDS order is v,w,u,0
+      const int dst = pos < S ? 2 * S + pos : pos - S;
+      F[k * G::FSTRIDE + dst] = static_cast<short>(val);
+    }
+    for (int k = lt; k < na; k += TS) F[k * G::FSTRIDE + 3 * S] = 0;
+    __syncthreads();
+  };
+
+  int ovf = 0;
+
+  if constexpr (MODE == STEP) {
+    stage(0, 1);
+    uint32_t nz = 0;
+    int chg = 0;
+#pragma unroll
+    for (int n = 0; n < G::NCH; ++n) {
+      if (!cv[n]) continue;
+      int acc[16];
+      unpack16(pk[n], acc);
+      rank1_16<S, true>(acc, ci[n], cj[n], cl[n], F, chg);
+      pk[n] = pack16(acc, nz, ovf);
+      if (live) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * (n * TS + lt), pk[n], ctail[n]);
+    }
+    bool any_nz, any_ovf;
+    if constexpr (TS == 256) {
+      any_nz = __syncthreads_or(nz != 0);
+      any_ovf = __syncthreads_or((ovf & ~255) != 0);
+    } else {
+      any_nz = team_any<TS>(nz != 0);
+      any_ovf = team_any<TS>((ovf & ~255) != 0);
+    }
+    if (lt == 0 && live) {
+      a.done[g] = any_nz ? 0 : 1;
+      if (a.overflow && any_ovf) a.overflow[g] = 1;
+    }
+  } else if constexpr (MODE == MANY || MODE == GENF) {
+    int acc[G::NCH][16];
+#pragma unroll
+    for (int n = 0; n < G::NCH; ++n) unpack16(pk[n], acc[n]);
+    int done_step = -1;
+    if constexpr (MODE == MANY && TS == 256) {
+      for (int k = tid; k < a.nact; k += kBlock) nzf[k] = 0;
+    }
+    for (int a0 = 0; a0 < a.nact; a0 += G::ATILE) {
+      const int na = min(G::ATILE, a.nact - a0);
+      stage(a0, na);
+      for (int k = 0; k < na; ++k) {
+        int chg = 0;
+        uint32_t nz = 0;
+#pragma unroll
+        for (int n = 0; n < G::NCH; ++n) {
+          if (!cv[n]) continue;
+          rank1_16<S, SUB>(acc[n], ci[n], cj[n], cl[n], F + k * G::FSTRIDE, chg);
+          if constexpr (MODE == MANY) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+              nz |= static_cast<uint32_t>(acc[n][t]);
+              ovf |= acc[n][t] + 128;
+            }
+          }
+        }
+        if constexpr (MODE == MANY) {
+          if constexpr (TS == 256) {
+            if (nz & 255) nzf[a0 + k] = 1;
+          } else {
+            if (!team_any<TS>((nz & 255) != 0) && done_step < 0) done_step = a0 + k;
+          }
+        }
+      }
+    }
+    uint32_t nz = 0;
+#pragma unroll
+    for (int n = 0; n < G::NCH; ++n) {
+      if (!cv[n]) continue;
+      pk[n] = pack16(acc[n], nz, ovf);  // GENF: the only range check (sum narrowed once)
+      if (live) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * (n * TS + lt), pk[n], ctail[n]);
+    }
+    bool any_ovf;
+    if constexpr (TS == 256) {
+      any_ovf = __syncthreads_or((ovf & ~255) != 0);  // also orders the nzf writes
+      if (MODE == MANY && tid == 0) {
+        for (int k = 0; k < a.nact; ++k)
+          if (!nzf[k]) { done_step = k; break; }
+      }
+    } else {
+      any_ovf = team_any<TS>((ovf & ~255) != 0);
+    }
+    if (lt == 0 && live) {
+      if constexpr (MODE == MANY) a.done_step[g] = done_step;
+      if (a.overflow && any_ovf) a.overflow[g] = 1;
+    }
+  } else {  // EXPAND
+    for (int a0 = 0; a0 < a.nact; a0 += G::ATILE) {
+      const int na = min(G::ATILE, a.nact - a0);
+      stage(a0, na);
+      for (int k = 0; k < na; ++k) {
+        const int64_t child = g * a.nact + a0 + k;
+        uint32_t nz = 0;
+        int chg = 0, covf = 0;
+#pragma unroll
+        for (int n = 0; n < G::NCH; ++n) {
+          if (!cv[n]) continue;
+          int acc[16];
+          unpack16(pk[n], acc);
+          rank1_16<S, true>(acc, ci[n], cj[n], cl[n], F + k * G::FSTRIDE, chg);
+          const uint4 q = pack16(acc, nz, covf);
+          if (live) store_chunk<G::TAIL>(a.out + child * a.out_stride + 16 * (n * TS + lt), q, ctail[n]);
+        }
+        bool any_nz, any_chg, any_ovf;
+        if constexpr (TS == 256) {
+          any_nz = __syncthreads_or(nz != 0);
+          any_chg = __syncthreads_or(chg != 0);
+          any_ovf = __syncthreads_or((covf & ~255) != 0);
+        } else {
+          any_nz = team_any<TS>(nz != 0);
+          any_chg = team_any<TS>(chg != 0);
+          any_ovf = team_any<TS>((covf & ~255) != 0);
+        }
+        if (lt == 0 && live) {
+          a.done[child] = any_nz ? 0 : 1;
+          if (a.changed) a.changed[child] = any_chg ? 1 : 0;
+          if (a.overflow && any_ovf) a.overflow[child] = 1;
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// S = 4 in registers: 4 lanes per game, lane q owns slice i = q (16 bytes = one dwordx4).
+// Tokens: 12 bytes per action = three dwords (u | v | w), read by every lane of the game.
+// =============================================================================================
+struct S4Factors {
+  int ui;        // -(u_i) for subtract modes, +u_i for GENF
+  int v[4], w[4];
+};
+
+template <bool SUB>
+__device__ __forceinline__ S4Factors s4_factors(const int* tok3, int q, int shift) {
+  const uint32_t du = tok3[0], dv = tok3[1], dw = tok3[2];
+  S4Factors f;
+  f.ui = __builtin_amdgcn_sbfe(static_cast<int>(du), 8 * q, 8) - shift;
+  if constexpr (SUB) f.ui = -f.ui;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f.v[t] = sbyte(dv, t) - shift;
+    f.w[t] = sbyte(dw, t) - shift;
+  }
+  return f;
+}
+
+__device__ __forceinline__ void s4_rank1(int (&acc)[16], const S4Factors& f, int& chg) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int uv = __mul24(f.ui, f.v[j]);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int p = __mul24(uv, f.w[l]);
+      acc[4 * j + l] += p;
+      chg |= p;
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  int64_t g = tid >> 2;
+  const int q = static_cast<int>(tid & 3);
+  const bool live = g < a.B;
+  if (!live) g = a.B - 1;
+  const int* tok = reinterpret_cast<const int*>(a.actions + g * a.nact * 12);
+  uint4 pk{0, 0, 0, 0};
+  if constexpr (MODE != GENF) pk = *reinterpret_cast<const uint4*>(a.in + g * a.in_stride + 16 * q);
+  int ovf = 0;
+
+  if constexpr (MODE == STEP) {
+    const S4Factors f = s4_factors<true>(tok, q, a.shift);
+    int acc[16], chg = 0;
+    uint32_t nz = 0;
+    unpack16(pk, acc);
+    s4_rank1(acc, f, chg);
+    pk = pack16(acc, nz, ovf);
+    if (live) *reinterpret_cast<uint4*>(a.out + g * a.out_stride + 16 * q) = pk;
+    const bool any_nz = team_any<4>(nz != 0);
+    const bool any_ovf = team_any<4>((ovf & ~255) != 0);
+    if (q == 0 && live) {
+      a.done[g] = any_nz ? 0 : 1;
+      if (a.overflow && any_ovf) a.overflow[g] = 1;
+    }
+  } else if constexpr (MODE == MANY || MODE == GENF) {
+    int acc[16];
+    unpack16(pk, acc);
+    int done_step = -1;
+    int t0 = tok[0], t1 = tok[1], t2 = tok[2];
+    for (int k = 0; k < a.nact; ++k) {
+      const int cur[3] = {t0, t1, t2};
+      if (k + 1 < a.nact) {  // prefetch the next action's tokens
+        t0 = tok[3 * (k + 1)];
+        t1 = tok[3 * (k + 1) + 1];
+        t2 = tok[3 * (k + 1) + 2];
+      }
+      const S4Factors f = s4_factors<MODE != GENF>(cur, q, a.shift);
+      int chg = 0;
+      s4_rank1(acc, f, chg);
+      if constexpr (MODE == MANY) {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          nz |= static_cast<uint32_t>(acc[t]);
+          ovf |= acc[t] + 128;
+        }
+        if (!team_any<4>((nz & 255) != 0) && done_step < 0) done_step = k;
+      }
+    }
+    uint32_t nz = 0;
+    pk = pack16(acc, nz, ovf);
+    if (live) *reinterpret_cast<uint4*>(a.out + g * a.out_stride + 16 * q) = pk;
+    const bool any_ovf = team_any<4>((ovf & ~255) != 0);
+    if (q == 0 && live) {
+      if constexpr (MODE == MANY) a.done_step[g] = done_step;
+      if (a.overflow && any_ovf) a.overflow[g] = 1;
+    }
+  } else {  // EXPAND
+    for (int k = 0; k < a.nact; ++k) {
+      const S4Factors f = s4_factors<true>(tok + 3 * k, q, a.shift);
+      const int64_t child = g * a.nact + k;
+      int acc[16], chg = 0, covf = 0;
+      uint32_t nz = 0;
+      unpack16(pk, acc);
+      s4_rank1(acc, f, chg);
+      const uint4 o = pack16(acc, nz, covf);
+      if (live) *reinterpret_cast<uint4*>(a.out + child * a.out_stride + 16 * q) = o;
+      const bool any_nz = team_any<4>(nz != 0);
+      const bool any_chg = team_any<4>(chg != 0);
+      const bool any_ovf = team_any<4>((covf & ~255) != 0);
+      if (q == 0 && live) {
+        a.done[child] = any_nz ? 0 : 1;
+        if (a.changed) a.changed[child] = any_chg ? 1 : 0;
+        if (a.overflow && any_ovf) a.overflow[child] = 1;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// terminal check / nnz, and reset
+// =============================================================================================
+
+// One wavefront per game, grid-stride over games; 16-byte loads when the layout allows it.
+__global__ __launch_bounds__(kBlock) void done_kernel(const int8_t* state, uint8_t* done, int32_t* nnz,
+                                                      int64_t B, int N, int64_t stride, int vec16) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  const int64_t nwave = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  for (int64_t g = wave; g < B; g += nwave) {
+    const int8_t* p = state + g * stride;
+    int cnt = 0;
+    int body = 0;
+    if (vec16) {
+      body = N & ~15;
+      for (int e = 16 * lane; e < body; e += 16 * 64) {
+        const uint4 q = *reinterpret_cast<const uint4*>(p + e);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          // count non-zero bytes of a dword: fold each byte to its low bit
+          uint32_t x = w[d];
+          x |= x >> 4;
+          x |= x >> 2;
+          x |= x >> 1;
+          cnt += __popc(x & 0x01010101u);
+        }
+      }
+    }
+    for (int e = body + lane; e < N; e += 64) cnt += p[e] != 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) {
+      done[g] = cnt == 0;
+      if (nnz) nnz[g] = cnt;
+    }
+  }
+}
+
+// state_out[b] <- template (S^3 bytes).  One workgroup per game, grid-stride.
+__global__ __launch_bounds__(kBlock) void broadcast_kernel(const int8_t* start, int8_t* out, int64_t B, int N,
+                                                           int64_t stride, int vec16) {
+  for (int64_t g = blockIdx.x; g < B; g += gridDim.x) {
+    int8_t* dst = out + g * stride;
+    int body = 0;
+    if (vec16) {
+      body = N & ~15;
+      for (int e = 16 * threadIdx.x; e < body; e += 16 * kBlock)
+        *reinterpret_cast<uint4*>(dst + e) = *reinterpret_cast<const uint4*>(start + e);
+    }
+    for (int e = body + threadIdx.x; e < N; e += kBlock) dst[e] = start[e];
+  }
+}
+
+// <n,n,n> tensor (reference utils.py:158-160): entry [p][q][r] = 1 iff p = a*n+j, q = j*n+c,
+// r = a*n+c for some a,j,c  <=>  p/n == r/n, q%n == r%n, p%n == q/n.
+__global__ __launch_bounds__(kBlock) void matmul_reset_kernel(int8_t* out, int64_t B, int n, int64_t stride) {
+  const int S = n * n, N = S * S * S;
+  for (int64_t g = blockIdx.x; g < B; g += gridDim.x) {
+    int8_t* dst = out + g * stride;
+    for (int e = threadIdx.x; e < N; e += kBlock) {
+      const int p = e / (S * S), rem = e - p * S * S, q = rem / S, r = rem - q * S;
+      dst[e] = (p / n == r / n) && (q % n == r % n) && (p % n == q / n);
+    }
+  }
+}
+
+}  // namespace tg
+
+// =============================================================================================
+// host side: validation, dispatch, C ABI
+// =============================================================================================
+static thread_local char g_err[512] = "";
+
+// shared with tg_gen.hip (same library); not part of the C ABI
+int tg_internal_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define fail tg_internal_fail
+
+namespace {
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(TG_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return TG_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
+
+int validate_common(const char* fn, int64_t B, int S, int64_t stride) {
+  if (B < 0) return fail(TG_ERR_INVALID, "%s: B=%lld < 0", fn, (long long)B);
+  if (S < 1 || S > TG_MAX_S) return fail(TG_ERR_INVALID, "%s: S=%d outside [1,%d]", fn, S, TG_MAX_S);
+  if (stride < (int64_t)S * S * S)
+    return fail(TG_ERR_INVALID, "%s: game_stride_bytes=%lld < S^3=%d", fn, (long long)stride, S * S * S);
+  return TG_OK;
+}
+
+unsigned capped_grid(int64_t blocks) {
+  const int64_t cap = 1 << 20;
+  return static_cast<unsigned>(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+template <int MODE>
+int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
+  using namespace tg;
+  if (a.B == 0) return TG_OK;
+  const bool al = (MODE == GENF || (aligned16(a.in) && a.in_stride % 16 == 0)) && aligned16(a.out) &&
+                  a.out_stride % 16 == 0;
+  const int64_t B = a.B;
+#define TG_TEAM(S_, TS_)                                                                        \
+  do {                                                                                          \
+    const int64_t blocks = (B + Geo<S_, TS_>::GPB - 1) / Geo<S_, TS_>::GPB;                     \
+    if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);              \
+    hipLaunchKernelGGL((team_kernel<S_, TS_, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a); \
+    return check_launch(fn);                                                                    \
+  } while (0)
+  if (al && a.S == 4 && aligned4(a.actions)) {
+    const int64_t blocks = (B * 4 + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
+    hipLaunchKernelGGL((s4_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+    return check_launch(fn);
+  }
+  if (al && a.S == 9) TG_TEAM(9, 64);
+  if (al && a.S == 16) TG_TEAM(16, 64);
+  if (al && a.S == 25) TG_TEAM(25, 256);
+#undef TG_TEAM
+  hipLaunchKernelGGL((slow_kernel<MODE>), dim3(capped_grid(B)), dim3(kBlock), 0, st, a);
+  return check_launch(fn);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_abi_version(void) { return TG_ABI_VERSION; }
+const char* tg_last_error(void) { return g_err; }
+
+int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions, uint8_t* done,
+               uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes, int shift,
+               tg_stream_t stream) {
+  if (int rc = validate_common("tg_step_i8", B, S, game_stride_bytes)) return rc;
+  if (B && (!state_in || !state_out || !actions || !done))
+    return fail(TG_ERR_INVALID, "tg_step_i8: null pointer");
+  tg::ApplyArgs a{state_in, state_out, actions, done, nullptr, nullptr, overflow, B,
+                  game_stride_bytes, game_stride_bytes, S, 1, shift};
+  return launch_apply<tg::STEP>("tg_step_i8", a, static_cast<hipStream_t>(stream));
+}
+
+int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
+                    int32_t* done_step, uint8_t* overflow, int64_t B, int S, int K,
+                    int64_t game_stride_bytes, int shift, tg_stream_t stream) {
+  if (int rc = validate_common("tg_step_many_i8", B, S, game_stride_bytes)) return rc;
+  if (K < 1 || K > TG_MAX_ACTIONS)
+    return fail(TG_ERR_INVALID, "tg_step_many_i8: K=%d outside [1,%d]", K, TG_MAX_ACTIONS);
+  if (B && (!state_in || !state_out || !actions || !done_step))
+    return fail(TG_ERR_INVALID, "tg_step_many_i8: null pointer");
+  tg::ApplyArgs a{state_in, state_out, actions, nullptr, done_step, nullptr, overflow, B,
+                  game_stride_bytes, game_stride_bytes, S, K, shift};
+  return launch_apply<tg::MANY>("tg_step_many_i8", a, static_cast<hipStream_t>(stream));
+}
+
+int tg_expand_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions, uint8_t* done,
+                 uint8_t* changed, uint8_t* overflow, int64_t B, int S, int k,
+                 int64_t in_stride_bytes, int64_t out_stride_bytes, int shift, tg_stream_t stream) {
+  if (int rc = validate_common("tg_expand_i8", B, S, in_stride_bytes)) return rc;
+  if (int rc = validate_common("tg_expand_i8", B, S, out_stride_bytes)) return rc;
+  if (k < 1 || k > TG_MAX_ACTIONS)
+    return fail(TG_ERR_INVALID, "tg_expand_i8: k=%d outside [1,%d]", k, TG_MAX_ACTIONS);
+  if (B && (!state_in || !state_out || !actions || !done))
+    return fail(TG_ERR_INVALID, "tg_expand_i8: null pointer");
+  if (state_in == state_out) return fail(TG_ERR_INVALID, "tg_expand_i8: in-place expansion is not defined");
+  tg::ApplyArgs a{state_in, state_out, actions, done, nullptr, changed, overflow, B,
+                  in_stride_bytes, out_stride_bytes, S, k, shift};
+  return launch_apply<tg::EXPAND>("tg_expand_i8", a, static_cast<hipStream_t>(stream));
+}
+
+int tg_gen_from_factors_i8(const int8_t* actions, int8_t* target_out, uint8_t* overflow, int64_t B,
+                           int S, int R, int64_t game_stride_bytes, int shift, tg_stream_t stream) {
+  if (int rc = validate_common("tg_gen_from_factors_i8", B, S, game_stride_bytes)) return rc;
+  if (R < 1 || R > TG_MAX_ACTIONS)
+    return fail(TG_ERR_INVALID, "tg_gen_from_factors_i8: R=%d outside [1,%d]", R, TG_MAX_ACTIONS);
+  if (B && (!actions || !target_out)) return fail(TG_ERR_INVALID, "tg_gen_from_factors_i8: null pointer");
+  tg::ApplyArgs a{nullptr, target_out, actions, nullptr, nullptr, nullptr, overflow, B,
+                  game_stride_bytes, game_stride_bytes, S, R, shift};
+  return launch_apply<tg::GENF>("tg_gen_from_factors_i8", a, static_cast<hipStream_t>(stream));
+}
+
+int tg_done_i8(const int8_t* state, uint8_t* done, int32_t* nnz, int64_t B, int S,
+               int64_t game_stride_bytes, tg_stream_t stream) {
+  if (int rc = validate_common("tg_done_i8", B, S, game_stride_bytes)) return rc;
+  if (B == 0) return TG_OK;
+  if (!state || !done) return fail(TG_ERR_INVALID, "tg_done_i8: null pointer");
+  const int vec16 = aligned16(state) && game_stride_bytes % 16 == 0;
+  const int64_t blocks = (B + 3) / 4;  // 4 wavefronts (games) per workgroup
+  hipLaunchKernelGGL(tg::done_kernel, dim3(capped_grid(blocks)), dim3(tg::kBlock), 0,
+                     static_cast<hipStream_t>(stream), state, done, nnz, B, S * S * S,
+                     game_stride_bytes, vec16);
+  return check_launch("tg_done_i8");
+}
+
+int tg_reset_matmul_i8(int8_t* state_out, int64_t B, int n, int64_t game_stride_bytes,
+                       tg_stream_t stream) {
+  if (n < 1 || n * n > TG_MAX_S) return fail(TG_ERR_INVALID, "tg_reset_matmul_i8: n=%d, need 1 <= n*n <= %d", n, TG_MAX_S);
+  if (int rc = validate_common("tg_reset_matmul_i8", B, n * n, game_stride_bytes)) return rc;
+  if (B == 0) return TG_OK;
+  if (!state_out) return fail(TG_ERR_INVALID, "tg_reset_matmul_i8: null pointer");
+  hipLaunchKernelGGL(tg::matmul_reset_kernel, dim3(capped_grid(B)), dim3(tg::kBlock), 0,
+                     static_cast<hipStream_t>(stream), state_out, B, n, game_stride_bytes);
+  return check_launch("tg_reset_matmul_i8");
+}
+
+int tg_reset_broadcast_i8(const int8_t* start, int8_t* state_out, int64_t B, int S,
+                          int64_t game_stride_bytes, tg_stream_t stream) {
+  if (int rc = validate_common("tg_reset_broadcast_i8", B, S, game_stride_bytes)) return rc;
+  if (B == 0) return TG_OK;
+  if (!start || !state_out) return fail(TG_ERR_INVALID, "tg_reset_broadcast_i8: null pointer");
+  const int vec16 = aligned16(start) && aligned16(state_out) && game_stride_bytes % 16 == 0;
+  hipLaunchKernelGGL(tg::broadcast_kernel, dim3(capped_grid(B)), dim3(tg::kBlock), 0,
+                     static_cast<hipStream_t>(stream), start, state_out, B, S * S * S,
+                     game_stride_bytes, vec16);
+  return check_launch("tg_reset_broadcast_i8");
+}
+
+}  // extern "C"

@@ -1,0 +1,333 @@
+"""Tensor-level wrappers over the C ABI (include/tensor_game.h).
+
+Every function takes PyTorch-ROCm tensors, checks device / dtype / layout on the host,
+and enqueues ONE kernel on the caller's current HIP stream (so calls can be captured in a
+``torch.cuda.graph``).  PyTorch is plumbing here: device memory and streams.  There is
+no CPU path: a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import TG_MAX_ACTIONS, TG_MAX_S, TG_MAX_VALUES, TensorGameError, call
+
+__all__ = [
+    "step", "prepare_step", "step_many", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
+    "gen_demos", "sample_basis", "change_basis", "as_tokens", "categorical_thresholds",
+    "alloc_states",
+]
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(dev: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _need_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise TensorGameError(name, -1, f"{name} must live on a ROCm device (got {t.device}); there is no CPU path")
+
+
+def _state_layout(state: torch.Tensor, name: str) -> Tuple[int, int, int]:
+    """(B, S, game_stride_bytes) of an int8 (B,S,S,S) tensor whose games are dense."""
+    _need_gpu(state, name)
+    if state.dtype != torch.int8 or state.dim() != 4 or not (state.shape[1] == state.shape[2] == state.shape[3]):
+        raise TensorGameError(name, -1, f"{name} must be int8 of shape (B,S,S,S), got {state.dtype} {tuple(state.shape)}")
+    B, S = state.shape[0], state.shape[1]
+    if B > 0 and state.stride()[1:] != (S * S, S, 1):
+        raise TensorGameError(name, -1, f"{name}: each game must be C-contiguous (S,S,S)")
+    stride = state.stride(0) if B > 1 else max(state.stride(0), S ** 3)
+    if stride < S ** 3:
+        raise TensorGameError(name, -1, f"{name}: game stride {stride} < S^3")
+    return B, S, stride
+
+
+def _tokens(actions: torch.Tensor, lead: Tuple[int, ...], S: int, dev: torch.device, name: str) -> torch.Tensor:
+    _need_gpu(actions, name)
+    if actions.dtype != torch.int8:
+        raise TensorGameError(name, -1, f"{name} must be int8 tokens (use ops.as_tokens), got {actions.dtype}")
+    if tuple(actions.shape) != (*lead, 3 * S):
+        raise TensorGameError(name, -1, f"{name} must have shape {(*lead, 3 * S)}, got {tuple(actions.shape)}")
+    if actions.device != dev:
+        raise TensorGameError(name, -1, f"{name} is on {actions.device}, state on {dev}")
+    return actions if actions.is_contiguous() else actions.contiguous()
+
+
+def _flag(t: Optional[torch.Tensor], shape: Tuple[int, ...], dtype, dev, name: str) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != dtype or tuple(t.shape) != shape or t.device != dev or not t.is_contiguous():
+        raise TensorGameError(name, -1, f"{name} must be contiguous {dtype} {shape} on {dev}")
+    return t
+
+
+def as_tokens(actions, device=None, check: bool = True) -> torch.Tensor:
+    """int64 (reference dtype, datasets.py:140) or any integer tensor -> int8 tokens.
+    ``check`` verifies the values fit int8 (one host sync); the reference never range-checks
+    tokens (utils.py:64-66), the build refuses values it cannot represent."""
+    t = torch.as_tensor(actions)
+    if t.dtype != torch.int8:
+        if t.is_floating_point():
+            raise TensorGameError("as_tokens", -1, "tokens must be integers")
+        if check and t.numel() and (int(t.min()) < -128 or int(t.max()) > 127):
+            raise TensorGameError("as_tokens", -1, "token outside int8 range")
+        t = t.to(torch.int8)
+    if device is not None:
+        t = t.to(device)
+    return t.contiguous()
+
+
+def alloc_states(B: int, S: int, device, pad_to: int = 16) -> torch.Tensor:
+    """Zeroed int8 (B,S,S,S) states whose game stride is S^3 rounded up to ``pad_to`` bytes
+    (16 keeps every game on the dwordx4 fast path; S=25 -> 15632)."""
+    n = S ** 3
+    stride = -(-n // pad_to) * pad_to
+    buf = torch.zeros((B, stride), dtype=torch.int8, device=device)
+    return buf[:, :n].unflatten(1, (S, S, S))
+
+
+def step(state, actions, out=None, done=None, overflow=None, shift: int = 1):
+    """state_out = state - u(x)v(x)w(actions); done[b] = state_out[b] all zero.
+    == reference get_child_states (act.py:266-275, k=1,T=1) + tensor_factorized per game
+    (utils.py:181-188).  ``out=state`` steps in place.  Returns (state_out, done)."""
+    B, S, stride = _state_layout(state, "state")
+    dev = state.device
+    actions = _tokens(actions, (B,), S, dev, "actions")
+    if out is None:
+        out = torch.empty_strided(state.shape, state.stride(), dtype=torch.int8, device=dev)
+    Bo, So, ostride = _state_layout(out, "out")
+    if (Bo, So) != (B, S) or (B > 1 and ostride != stride) or out.device != dev:
+        raise TensorGameError("step", -1, "out must match state's shape, stride and device")
+    if done is None:
+        done = torch.empty((B,), dtype=torch.uint8, device=dev)
+    done = _flag(done, (B,), torch.uint8, dev, "done")
+    overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
+    with torch.cuda.device(dev):
+        call("tg_step_i8", _ptr(state), _ptr(out), _ptr(actions), _ptr(done), _ptr(overflow),
+             B, S, stride, int(shift), _stream(dev))
+    return out, done
+
+
+def prepare_step(state, actions_seq, done, overflow=None, shift: int = 1):
+    """Validate once, launch many: returns ``launch(k)`` that enqueues one in-place
+    ``tg_step_i8`` with ``actions_seq[k]`` on the current stream with no per-call checks
+    (for rollouts and hipGraph capture, where Python overhead would dominate a 2 us kernel)."""
+    B, S, stride = _state_layout(state, "state")
+    dev = state.device
+    acts = [_tokens(a, (B,), S, dev, "actions") for a in actions_seq]
+    done = _flag(done, (B,), torch.uint8, dev, "done")
+    overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
+    fn = _lib.lib.tg_step_i8
+    sp, dp, op = _ptr(state), _ptr(done), _ptr(overflow)
+    aps = [_ptr(a) for a in acts]
+    Bc, Sc, stc, shc = C.c_int64(B), C.c_int(S), C.c_int64(stride), C.c_int(int(shift))
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+
+    def launch(k: int) -> None:
+        rc = fn(sp, sp, aps[k], dp, op, Bc, Sc, stc, shc, C.c_void_p(torch.cuda.current_stream(index).cuda_stream))
+        if rc != 0:
+            raise TensorGameError("tg_step_i8", rc, _lib.lib.tg_last_error().decode())
+
+    launch.keepalive = (state, acts, done, overflow)  # the raw pointers above must stay valid
+    return launch
+
+
+def step_many(state, actions, out=None, done_step=None, overflow=None, shift: int = 1):
+    """K sequential steps, state resident on chip.  actions int8 (B,K,3S).
+    == reference SyntheticDemoDataset._take_actions (datasets.py:144-153).
+    Returns (state_out, done_step int32: first step whose post-state is zero, or -1)."""
+    B, S, stride = _state_layout(state, "state")
+    dev = state.device
+    if actions.dim() != 3:
+        raise TensorGameError("step_many", -1, "actions must be (B,K,3S)")
+    K = actions.shape[1]
+    actions = _tokens(actions, (B, K), S, dev, "actions")
+    if out is None:
+        out = torch.empty_strided(state.shape, state.stride(), dtype=torch.int8, device=dev)
+    Bo, So, ostride = _state_layout(out, "out")
+    if (Bo, So) != (B, S) or (B > 1 and ostride != stride) or out.device != dev:
+        raise TensorGameError("step_many", -1, "out must match state's shape, stride and device")
+    if done_step is None:
+        done_step = torch.empty((B,), dtype=torch.int32, device=dev)
+    done_step = _flag(done_step, (B,), torch.int32, dev, "done_step")
+    overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
+    with torch.cuda.device(dev):
+        call("tg_step_many_i8", _ptr(state), _ptr(out), _ptr(actions), _ptr(done_step), _ptr(overflow),
+             B, S, K, stride, int(shift), _stream(dev))
+    return out, done_step
+
+
+def expand(state, actions, out=None, done=None, changed=None, overflow=None, shift: int = 1):
+    """k children per parent.  actions int8 (B,k,3S) -> children int8 (B,k,S,S,S), done (B,k),
+    changed (B,k).  == reference get_child_states (act.py:266-275) with k>1, T=1, plus the
+    per-game form of remove_null_actions (utils.py:191-194)."""
+    B, S, stride = _state_layout(state, "state")
+    dev = state.device
+    if actions.dim() != 3:
+        raise TensorGameError("expand", -1, "actions must be (B,k,3S)")
+    k = actions.shape[1]
+    actions = _tokens(actions, (B, k), S, dev, "actions")
+    if out is None:
+        out = alloc_states(B * k, S, dev).unflatten(0, (B, k))
+    if out.dtype != torch.int8 or tuple(out.shape) != (B, k, S, S, S) or out.device != dev:
+        raise TensorGameError("expand", -1, f"out must be int8 {(B, k, S, S, S)} on {dev}")
+    _, _, ostride = _state_layout(out.flatten(0, 1), "out")
+    if done is None:
+        done = torch.empty((B, k), dtype=torch.uint8, device=dev)
+    if changed is None:
+        changed = torch.empty((B, k), dtype=torch.uint8, device=dev)
+    done = _flag(done, (B, k), torch.uint8, dev, "done")
+    changed = _flag(changed, (B, k), torch.uint8, dev, "changed")
+    overflow = _flag(overflow, (B, k), torch.uint8, dev, "overflow")
+    with torch.cuda.device(dev):
+        call("tg_expand_i8", _ptr(state), _ptr(out), _ptr(actions), _ptr(done), _ptr(changed),
+             _ptr(overflow), B, S, k, stride, ostride, int(shift), _stream(dev))
+    return out, done, changed
+
+
+def done(state, want_nnz: bool = False):
+    """done[b] = head of game b is all zero (== tensor_factorized, utils.py:181-188, per game);
+    nnz[b] = number of non-zero entries (the rank bound of training.py:266)."""
+    B, S, stride = _state_layout(state, "state")
+    dev = state.device
+    d = torch.empty((B,), dtype=torch.uint8, device=dev)
+    nnz = torch.empty((B,), dtype=torch.int32, device=dev) if want_nnz else None
+    with torch.cuda.device(dev):
+        call("tg_done_i8", _ptr(state), _ptr(d), _ptr(nnz), B, S, stride, _stream(dev))
+    return (d, nnz) if want_nnz else d
+
+
+def reset_matmul(out, n: int):
+    """every game <- <n,n,n> (== build_matmul_tensor(1,n,n,n)[0], utils.py:143-161)."""
+    B, S, stride = _state_layout(out, "out")
+    if S != n * n:
+        raise TensorGameError("reset_matmul", -1, f"S={S} != n*n={n * n}")
+    with torch.cuda.device(out.device):
+        call("tg_reset_matmul_i8", _ptr(out), B, int(n), stride, _stream(out.device))
+    return out
+
+
+def reset_broadcast(out, start):
+    """every game <- start (int8 (S,S,S) on the same device)."""
+    B, S, stride = _state_layout(out, "out")
+    _need_gpu(start, "start")
+    if start.dtype != torch.int8 or tuple(start.shape) != (S, S, S) or start.device != out.device:
+        raise TensorGameError("reset_broadcast", -1, f"start must be int8 {(S, S, S)} on {out.device}")
+    start = start.contiguous()
+    with torch.cuda.device(out.device):
+        call("tg_reset_broadcast_i8", _ptr(start), _ptr(out), B, S, stride, _stream(out.device))
+    return out
+
+
+def gen_from_factors(actions, S: int, out=None, overflow=None, shift: int = 1):
+    """target[b] = sum_r tensor(actions[b][r]); actions int8 (B,R,3S).  The deterministic half
+    of create_synthetic_demo (utils.py:218-232) / uvw_to_demo (utils.py:40-53)."""
+    _need_gpu(actions, "actions")
+    if actions.dim() != 3:
+        raise TensorGameError("gen_from_factors", -1, "actions must be (B,R,3S)")
+    B, R = actions.shape[:2]
+    dev = actions.device
+    actions = _tokens(actions, (B, R), S, dev, "actions")
+    if out is None:
+        out = alloc_states(B, S, dev)
+    Bo, So, stride = _state_layout(out, "out")
+    if (Bo, So) != (B, S) or out.device != dev:
+        raise TensorGameError("gen_from_factors", -1, "out shape/device mismatch")
+    overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
+    with torch.cuda.device(dev):
+        call("tg_gen_from_factors_i8", _ptr(actions), _ptr(out), _ptr(overflow), B, S, R, stride,
+             int(shift), _stream(dev))
+    return out
+
+
+def categorical_thresholds(probs: Sequence[float]) -> np.ndarray:
+    """uint32 cdf thresholds of a categorical distribution (normalised like
+    torch.distributions.Categorical, reference utils.py:198): a 32-bit draw d selects
+    values[#{t : d >= t}]."""
+    p = np.asarray(probs, dtype=np.float64)
+    if p.ndim != 1 or len(p) < 1 or len(p) > TG_MAX_VALUES or (p < 0).any() or p.sum() <= 0:
+        raise TensorGameError("categorical_thresholds", -1, f"probs must be 1..{TG_MAX_VALUES} non-negative weights")
+    cdf = np.cumsum(p) / p.sum()
+    return np.minimum(np.floor(cdf[:-1] * 4294967296.0 + 0.5), 4294967295.0).astype(np.uint32)
+
+
+def _dist(values, probs, name):
+    vals = np.asarray(values, dtype=np.int64)
+    if vals.ndim != 1 or len(vals) != len(probs) or (np.abs(vals) > 127).any():
+        raise TensorGameError(name, -1, "values must be int8 and match probs")
+    thr = categorical_thresholds(probs)
+    p = np.asarray(probs, dtype=np.float64)
+    if not ((vals != 0) & (p > 0)).any():
+        raise TensorGameError(name, -1, "the distribution can never draw a non-zero factor value")
+    vals8 = vals.astype(np.int8)
+    return (thr, vals8, thr.ctypes.data_as(C.c_void_p), vals8.ctypes.data_as(C.c_void_p), len(vals8))
+
+
+def gen_demos(B: int, S: int, R: int, device, values=(-1, 0, 1), probs=(0.15, 0.7, 0.15), shift: int = 1,
+              seed: int = 0, game_id_offset: int = 0, basis=None, target=None, actions=None, overflow=None):
+    """The synthetic-demonstration generator (== create_synthetic_demo, utils.py:203-233 /
+    SyntheticDemoDataset._create_synthetic_demos, datasets.py:124-142).  Returns
+    (actions int8 (B,R,3S), target int8 (B,S,S,S)).  Deterministic in (seed, global game id)."""
+    dev = torch.device(device)
+    thr, vals, thr_p, val_p, nv = _dist(values, probs, "gen_demos")
+    if target is None:
+        target = alloc_states(B, S, dev)
+    Bo, So, stride = _state_layout(target, "target")
+    if actions is None:
+        actions = torch.empty((B, R, 3 * S), dtype=torch.int8, device=dev)
+    if (Bo, So) != (B, S) or tuple(actions.shape) != (B, R, 3 * S) or actions.dtype != torch.int8 \
+            or not actions.is_contiguous() or actions.device != target.device:
+        raise TensorGameError("gen_demos", -1, "target/actions shape, dtype or device mismatch")
+    dev = target.device
+    overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
+    if basis is not None:
+        if basis.dtype != torch.int8 or tuple(basis.shape) != (B, 3, S, S) or basis.device != dev:
+            raise TensorGameError("gen_demos", -1, f"basis must be int8 {(B, 3, S, S)} on {dev}")
+        basis = basis.contiguous()
+    with torch.cuda.device(dev):
+        call("tg_gen_demos_i8", _ptr(target), _ptr(actions), _ptr(overflow), B, S, R, thr_p, val_p, nv,
+             int(shift), C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(game_id_offset), _ptr(basis), stride,
+             _stream(dev))
+    return actions, target
+
+
+def sample_basis(B: int, S: int, device, values=(-1, 0, 1), probs=(0.05, 0.9, 0.05), seed: int = 0,
+                 game_id_offset: int = 0, want_factors: bool = False):
+    """Three random unimodular matrices per game, P = L @ U (not in the reference)."""
+    dev = torch.device(device)
+    thr, vals, thr_p, val_p, nv = _dist(values, probs, "sample_basis")
+    P = torch.empty((B, 3, S, S), dtype=torch.int8, device=dev)
+    L = torch.empty_like(P) if want_factors else None
+    U = torch.empty_like(P) if want_factors else None
+    with torch.cuda.device(P.device):
+        call("tg_sample_basis_i8", _ptr(P), _ptr(L), _ptr(U), B, S, thr_p, val_p, nv,
+             C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(game_id_offset), _stream(P.device))
+    return (P, L, U) if want_factors else P
+
+
+def change_basis(state, basis, out=None, overflow=None):
+    """T'[a,b,c] = sum A[a,i] B[b,j] C[c,k] T[i,j,k]; basis int32 (B,3,S,S)."""
+    B, S, stride = _state_layout(state, "state")
+    dev = state.device
+    if basis.dtype != torch.int32 or tuple(basis.shape) != (B, 3, S, S) or basis.device != dev:
+        raise TensorGameError("change_basis", -1, f"basis must be int32 {(B, 3, S, S)} on {dev}")
+    basis = basis.contiguous()
+    if out is None:
+        out = torch.empty_strided(state.shape, state.stride(), dtype=torch.int8, device=dev)
+    Bo, So, ostride = _state_layout(out, "out")
+    if (Bo, So) != (B, S) or (B > 1 and ostride != stride):
+        raise TensorGameError("change_basis", -1, "out must match state's shape and stride")
+    if out.data_ptr() == state.data_ptr():
+        raise TensorGameError("change_basis", -1, "in-place change of basis is not supported")
+    overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
+    with torch.cuda.device(dev):
+        call("tg_change_basis_i8", _ptr(state), _ptr(basis), _ptr(out), _ptr(overflow), B, S, stride, _stream(dev))
+    return out

@@ -1,0 +1,392 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Bit-exact everywhere (integer/byte work).  Run on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import mat_mul_amd
+from mat_mul_amd import TensorGameEnv, SyntheticDemos, functional as F, ops
+from oracle import tensor_game as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def padded(states_np):
+    """int8 (B,S,S,S) numpy -> device tensor with a 16-byte-multiple game stride (fast path)."""
+    B, S = states_np.shape[0], states_np.shape[1]
+    t = ops.alloc_states(B, S, DEV)
+    t.copy_(torch.from_numpy(np.ascontiguousarray(states_np)))
+    return t
+
+
+def rand_case(rng, B, S, k=None, lo=-2, hi=3, terminal_every=5):
+    st = rng.integers(lo, hi, size=(B, S, S, S)).astype(np.int8)
+    shape = (B, 3 * S) if k is None else (B, k, 3 * S)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=shape).astype(np.int8)
+    first = ac if k is None else ac[:, 0]
+    for b in range(0, B, terminal_every):  # terminal games: state == action tensor
+        st[b] = O.action_to_tensor(first[b]).astype(np.int8)
+    return st, ac
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _native_loaded():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    assert mat_mul_amd._lib.lib.tg_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libtensorgame.so" in maps, "the HIP library is not the one loaded"
+
+
+# ------------------------------------------------------------------ golden fixtures via the C ABI
+def test_strassen_replay_golden(golden):
+    g = golden("strassen")
+    env = TensorGameEnv(1, 4, DEV)
+    state = env.reset()
+    assert np.array_equal(host(state)[0], g["replay"][0])            # reset == build_matmul_tensor(1,2,2,2)
+    for k in range(7):
+        state, done = env.step(dev(g["tokens"][k][None]))
+        assert np.array_equal(host(state)[0], g["replay"][k + 1])
+        assert int(done[0]) == int(g["done"][k + 1])
+        assert int(env.nnz()[0]) == [12, 12, 12, 10, 8, 4, 0][k]
+    assert not env.any_overflow()
+    env.reset()
+    state, done_step = env.step_many(dev(g["tokens"][None]))
+    assert not host(state).any() and host(done_step).tolist() == [6]
+    # reference-named functions
+    tensor, tokens = F.uvw_to_demo(dev(g["uu"]), dev(g["vv"]), dev(g["ww"]), DEV)
+    assert np.array_equal(host(tensor), g["tensor"]) and np.array_equal(host(tokens), g["tokens"])
+    assert bool(F.tensor_factorized(state.unsqueeze(1)))
+    out = F.take_actions(list(dev(g["tokens"])), dev(g["tensor"]))
+    assert not host(out).any()
+
+
+def test_strassen_dataset_448_golden(golden):
+    g = golden("strassen")
+    st = padded(g["ds_states"])
+    new, done = ops.step(st, dev(g["ds_actions"]), shift=2)
+    new_o, done_o, _ = O.step_i8(g["ds_states"], g["ds_actions"], shift=2)
+    assert np.array_equal(host(new), new_o) and np.array_equal(host(done), done_o)
+    assert np.array_equal(host(done).astype(bool), g["ds_rewards"] == -1) and int(done.sum()) == 7
+
+
+def test_build_matmul_tensor_golden(golden):
+    g = golden("matmul_tensors")
+    for n in (2, 3, 4, 5):
+        for T in (1, 2):
+            assert np.array_equal(host(F.build_matmul_tensor(T, n, n, n, DEV)), g[f"n{n}_t{T}"])
+        env = TensorGameEnv(37, n * n, DEV)
+        s = host(env.reset())
+        assert all(np.array_equal(s[b], g[f"n{n}_t1"][0]) for b in (0, 17, 36))
+        assert host(env.nnz()).tolist() == [n ** 3] * 37
+
+
+def test_get_child_states_golden(golden):
+    g = golden("step_cases")
+    tags = sorted({k.rsplit("_", 1)[0] for k in g.files if k.endswith("_state")})
+    assert len(tags) == 12
+    for tag in tags:
+        st, ac = g[tag + "_state"], g[tag + "_actions"]
+        B, k = ac.shape[:2]
+        kids = F.get_child_states(dev(st), dev(ac))
+        assert len(kids) == k
+        got = np.stack([host(c) for c in kids], axis=1)
+        assert np.array_equal(got, g[tag + "_children"]), tag
+        children, done, changed = ops.expand(padded(st[:, 0]), dev(ac))
+        assert np.array_equal(host(children), g[tag + "_children"][:, :, 0]), tag
+        assert np.array_equal(host(done), g[tag + "_done"]), tag
+        assert np.array_equal(host(changed), g[tag + "_changed"]), tag
+        assert F.remove_null_actions(dev(st), kids) == g[tag + "_nonnull_batch"].tolist(), tag
+        tf = [bool(F.tensor_factorized(c)) for c in kids]
+        assert tf == g[tag + "_tf_verbatim"].astype(bool).tolist(), tag
+        new, d1 = ops.step(padded(st[:, 0]), dev(ac[:, 0]))
+        assert np.array_equal(host(new), g[tag + "_children"][:, 0, 0]) and np.array_equal(host(d1), g[tag + "_done"][:, 0])
+
+
+def test_action_to_tensor_golden(golden):
+    g = golden("action_to_tensor")
+    for S in (4, 9, 16, 25):
+        ac = g[f"S{S}_actions"]
+        assert np.array_equal(host(F.action_to_tensor(dev(ac))), g[f"S{S}_batched"])
+        assert np.array_equal(host(F.action_to_tensor(dev(ac[2]))), g[f"S{S}_single"][2])
+        assert np.array_equal(host(F.action_to_tensor(dev(ac), shift=2)), g[f"S{S}_shift2"])
+    wide = g["wide_tensor"]
+    ovf = torch.zeros(5, dtype=torch.uint8, device=DEV)
+    out = ops.gen_from_factors(dev(g["wide_actions"])[:, None], 4, overflow=ovf)
+    assert np.array_equal(host(out), wide.astype(np.int8))
+    assert np.array_equal(host(ovf).astype(bool), ((wide < -128) | (wide > 127)).reshape(5, -1).any(axis=1))
+
+
+def test_synthetic_demo_golden(golden):
+    g = golden("synthetic_demos")
+    names = sorted(k[: -len("_tokens")] for k in g.files if k.endswith("_tokens") and "_item" not in k)
+    for nm in names:
+        tok, tgt = g[nm + "_tokens"], g[nm + "_target"]
+        S = tgt.shape[-1]
+        out = ops.gen_from_factors(dev(tok[None]), S)
+        assert np.array_equal(host(out)[0], tgt), nm
+        fin, done_step = ops.step_many(padded(tgt[None]), dev(tok[None]))
+        assert not host(fin).any() and 0 <= int(done_step[0]) < len(tok)
+    names = sorted(k[: -len("_suffix_states")] for k in g.files if k.endswith("_suffix_states"))
+    for nm in names:
+        tok, tgt, suf = g[nm + "_tokens"], g[nm + "_target"], g[nm + "_suffix_states"]
+        for i in range(len(tok)):
+            assert np.array_equal(host(F.take_actions(dev(tok[i + 1:]), dev(tgt))), suf[i]), (nm, i)
+
+
+# ------------------------------------------------------------------ seeded random vs the oracle
+@pytest.mark.parametrize("S", [1, 2, 3, 4, 5, 8, 9, 16, 25, 32])
+@pytest.mark.parametrize("B", [1, 3, 70, 257])
+def test_step_matches_oracle(S, B):
+    if S >= 25 and B > 70:
+        B = 33
+    rng = np.random.default_rng(S * 1000 + B)
+    st, ac = rand_case(rng, B, S)
+    want, want_done, want_ovf = O.step_i8(st, ac)
+    for layout in ("padded", "packed", "offset"):
+        if layout == "padded":
+            t = padded(st)
+        elif layout == "packed":
+            t = dev(st)
+        else:  # games start 3 bytes into a buffer: nothing is aligned -> byte path
+            buf = torch.zeros(B * S ** 3 + 3, dtype=torch.int8, device=DEV)
+            t = buf[3:].view(B, S, S, S)
+            t.copy_(dev(st))
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        out, done = ops.step(t, dev(ac), overflow=ovf)
+        assert np.array_equal(host(out), want), (S, B, layout)
+        assert np.array_equal(host(done), want_done), (S, B, layout)
+        assert np.array_equal(host(t), st), "input must be untouched out of place"
+        assert not host(ovf).any() and not want_ovf.any()
+        out2, done2 = ops.step(t, dev(ac), out=t)  # in place
+        assert out2.data_ptr() == t.data_ptr()
+        assert np.array_equal(host(t), want) and np.array_equal(host(done2), want_done)
+    assert want_done.sum() >= 1
+
+
+@pytest.mark.parametrize("S", [4, 9, 16, 25, 6])
+def test_step_wide_tokens_and_overflow(S):
+    rng = np.random.default_rng(77 + S)
+    B = 41
+    st = rng.integers(-128, 128, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.integers(-3, 6, size=(B, 3 * S)).astype(np.int8)
+    ac[::2] = rng.integers(0, 3, size=(len(ac[::2]), 3 * S))
+    for shift in (1, 2, -1):
+        want, want_done, want_ovf = O.step_i8(st, ac, shift=shift)
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        out, done = ops.step(padded(st), dev(ac), overflow=ovf, shift=shift)
+        assert np.array_equal(host(out), want) and np.array_equal(host(done), want_done)
+        assert np.array_equal(host(ovf), want_ovf) and want_ovf.any() and not want_ovf.all()
+        sticky = torch.ones(B, dtype=torch.uint8, device=DEV)           # never cleared by a call
+        ops.step(padded(st), dev(ac), overflow=sticky, shift=shift)
+        assert host(sticky).all()
+
+
+@pytest.mark.parametrize("S,B,K", [(4, 130, 7), (4, 5, 40), (9, 33, 12), (16, 9, 70), (25, 3, 130), (5, 6, 9), (2, 3, 3)])
+def test_step_many_matches_oracle(S, B, K):
+    rng = np.random.default_rng(S * 31 + K)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, K, 3 * S)).astype(np.int8)
+    st = rng.integers(-1, 2, size=(B, S, S, S)).astype(np.int8)
+    for b in range(0, B, 2):  # these games hit zero exactly after step b % K
+        kk = b % K
+        st[b] = O.gen_from_factors_i8(ac[b:b + 1, :kk + 1])[0][0]
+    want, want_ds, want_ovf = O.step_many_i8(st, ac)
+    for t in (padded(st), dev(st)):
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        out, ds = ops.step_many(t, dev(ac), overflow=ovf)
+        assert np.array_equal(host(out), want) and np.array_equal(host(ds), want_ds), (S, B, K)
+        assert np.array_equal(host(ovf), want_ovf)
+    assert (want_ds >= 0).sum() >= B // 2
+    # K single steps == one step_many
+    t = padded(st)
+    for k in range(K):
+        ops.step(t, dev(ac[:, k]), out=t)
+    assert np.array_equal(host(t), want)
+
+
+@pytest.mark.parametrize("S,B,k", [(4, 67, 8), (9, 5, 5), (16, 6, 3), (25, 2, 4), (3, 4, 2), (4, 1, 130)])
+def test_expand_matches_oracle(S, B, k):
+    rng = np.random.default_rng(S + 100 * k)
+    st, ac = rand_case(rng, B, S, k=k)
+    ac[1 % B, k - 1, :S] = 1  # null action (u = 0)
+    want, want_done, want_chg, _ = O.expand_i8(st, ac)
+    for t in (padded(st), dev(st)):
+        kids, done, chg = ops.expand(t, dev(ac))
+        assert np.array_equal(host(kids), want) and np.array_equal(host(done), want_done)
+        assert np.array_equal(host(chg), want_chg)
+    assert want_done.any() and not want_chg.all()
+
+
+def test_done_and_nnz():
+    rng = np.random.default_rng(5)
+    for S, B in [(4, 300), (9, 50), (16, 20), (25, 7), (7, 11)]:
+        st = (rng.random((B, S, S, S)) < 0.02).astype(np.int8) * rng.integers(-3, 4, size=(B, S, S, S)).astype(np.int8)
+        st[::3] = 0
+        for t in (padded(st), dev(st)):
+            d, nnz = ops.done(t, want_nnz=True)
+            assert np.array_equal(host(d), O.done_per_game(st).astype(np.uint8))
+            assert np.array_equal(host(nnz), O.nnz_per_game(st))
+
+
+# ------------------------------------------------------------------ generator
+@pytest.mark.parametrize("S,B,R", [(4, 300, 7), (9, 40, 12), (16, 12, 20), (25, 5, 30), (5, 9, 4)])
+def test_generator_bit_exact(S, B, R):
+    probs, values = (0.15, 0.7, 0.15), (-1, 0, 1)
+    thr = O.categorical_thresholds(probs)
+    want_tok, want_tgt, want_ovf = O.gen_demos_i8(B, S, R, thr, values, 1, seed=1234, game_id_offset=1000)
+    ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    tok, tgt = ops.gen_demos(B, S, R, DEV, values=values, probs=probs, seed=1234, game_id_offset=1000, overflow=ovf)
+    assert np.array_equal(host(tok), want_tok) and np.array_equal(host(tgt), want_tgt)
+    assert np.array_equal(host(ovf), want_ovf)
+    # sharding invariance: two shards == one batch (section 8e)
+    h = B // 3
+    a_tok, a_tgt = ops.gen_demos(h, S, R, DEV, seed=1234, game_id_offset=1000)
+    b_tok, b_tgt = ops.gen_demos(B - h, S, R, DEV, seed=1234, game_id_offset=1000 + h)
+    assert np.array_equal(np.concatenate([host(a_tok), host(b_tok)]), want_tok)
+    assert np.array_equal(np.concatenate([host(a_tgt), host(b_tgt)]), want_tgt)
+    # other distributions / shift, more categories
+    thr5 = O.categorical_thresholds((1, 2, 10, 2, 1))
+    w_tok, w_tgt, _ = O.gen_demos_i8(B, S, R, thr5, (-2, -1, 0, 1, 2), 2, seed=7)
+    g_tok, g_tgt = ops.gen_demos(B, S, R, DEV, values=(-2, -1, 0, 1, 2), probs=(1, 2, 10, 2, 1), shift=2, seed=7)
+    assert np.array_equal(host(g_tok), w_tok) and np.array_equal(host(g_tgt), w_tgt)
+
+
+def test_generator_distribution_vs_reference(golden):
+    from scipy import stats
+    g = golden("sampler_stats")
+    for S, probs, key in [(4, (0.15, 0.7, 0.15), "S4_p70"), (9, (0.15, 0.7, 0.15), "S9_p70"), (4, (0.1, 0.8, 0.1), "S4_p80")]:
+        tok, _ = ops.gen_demos(4096, S, 3, DEV, probs=probs, seed=2026)
+        f = host(tok).astype(np.int64) - 1
+        assert (f.reshape(-1, S) != 0).any(axis=1).all()
+        ours = np.array([(f == v).sum() for v in (-1, 0, 1)])
+        _, p, _, _ = stats.chi2_contingency(np.stack([ours, g[key + "_value_counts"]]))
+        assert p > 1e-3, (key, ours, p)
+
+
+def test_synthetic_demos_class_matches_reference_framing(golden):
+    """SyntheticDemos.batch == the reference's __getitem__ arithmetic on the same tokens."""
+    demos = SyntheticDemos(max_actions=6, n_demos=9, dim_t=3, dim_3d=4, device=DEV, seed=11)
+    tok, tgt = host(demos.action_seq), host(demos.target_tensor)
+    for ia in range(6):
+        state, scalar, action, reward = demos.batch(ia)
+        for d in (0, 4, 8):
+            frames, sc, act, rw = O.demo_getitem(list(tok[d]), tgt[d], ia, 3)
+            assert np.array_equal(host(state)[d], frames)
+            assert float(scalar[d]) == sc and float(reward[d]) == rw and np.array_equal(host(action)[d], act)
+    seq, target = F.create_synthetic_demo((-1, 0, 1), (0.1, 0.8, 0.1), 5, 4, 1, seed=3, device=DEV)
+    w_tok, w_tgt, _ = O.gen_demos_i8(1, 4, 5, O.categorical_thresholds((0.1, 0.8, 0.1)), (-1, 0, 1), 1, seed=3)
+    assert np.array_equal(np.stack([host(a) for a in seq]), w_tok[0]) and np.array_equal(host(target), w_tgt[0])
+
+
+# ------------------------------------------------------------------ change of basis (A12, parity unpinned: invariants)
+@pytest.mark.parametrize("S", [4, 9, 16, 25, 6])
+def test_basis(S):
+    B = 7
+    bp = (0.2, 0.6, 0.2) if S <= 9 else (0.03, 0.94, 0.03)
+    thr = O.categorical_thresholds(bp)
+    P_o, L_o, U_o = O.sample_basis(B, S, thr, (-1, 0, 1), seed=21, game_id_offset=5)
+    P, L, U = ops.sample_basis(B, S, DEV, probs=bp, seed=21, game_id_offset=5, want_factors=True)
+    assert np.array_equal(host(P), P_o) and np.array_equal(host(L), L_o) and np.array_equal(host(U), U_o)
+    fthr = O.categorical_thresholds((0.15, 0.7, 0.15))
+    R = 4
+    tok_o, tgt_o, ovf_o = O.gen_demos_i8(B, S, R, fthr, (-1, 0, 1), 1, seed=9, basis=P_o)
+    ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    tok, tgt = ops.gen_demos(B, S, R, DEV, seed=9, basis=P, overflow=ovf)
+    assert np.array_equal(host(tok), tok_o) and np.array_equal(host(tgt), tgt_o) and np.array_equal(host(ovf), ovf_o)
+    # tensor-level change of basis == oracle, == factor-level transform, inverse restores
+    plain_tok, plain_tgt = ops.gen_demos(B, S, R, DEV, seed=9)
+    ovf2 = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    moved = ops.change_basis(plain_tgt, P.to(torch.int32), overflow=ovf2)
+    moved_o, movf_o = O.change_basis_i8(host(plain_tgt), P_o)
+    assert np.array_equal(host(moved), moved_o) and np.array_equal(host(ovf2), movf_o)
+    ok = (movf_o == 0) & (ovf_o == 0)
+    assert ok.any() and np.array_equal(host(moved)[ok], tgt_o[ok])
+    Pinv = O.unimodular_inverse(L_o, U_o)
+    if np.abs(Pinv).max() < 2 ** 31:
+        back = ops.change_basis(moved, dev(Pinv.astype(np.int32)))
+        assert np.array_equal(host(back)[ok], host(plain_tgt)[ok])
+    eye = torch.eye(S, dtype=torch.int32, device=DEV).expand(B, 3, S, S).contiguous()
+    assert np.array_equal(host(ops.change_basis(plain_tgt, eye)), host(plain_tgt))
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE configs)
+@pytest.mark.parametrize("S,B,R", [(4, 65536, 7), (16, 8192, 20), (25, 4096, 64), (9, 20000, 12)])
+def test_full_size_generate_replay_terminate(S, B, R):
+    """cfg2/cfg3/cfg5-per-GPU: generator -> replay the demo's own actions -> every game reaches
+    zero exactly at the last step (generator, step, step_many and done agree)."""
+    demos = SyntheticDemos(R, B, 1, S, DEV, seed=S)
+    assert not bool(demos.overflow.any())
+    env = TensorGameEnv(B, S, DEV)
+    env.reset(demos.target_tensor)
+    rev = demos.action_seq.flip(1).contiguous()
+    for k in range(R):
+        state, done = env.step(rev[:, k])
+        if k < R - 1:
+            # a game may reach zero early only if the remaining terms cancel; it must then leave zero again
+            pass
+    assert bool(done.all()) and not bool(state.any()) and not env.any_overflow()
+    assert int(env.nnz().sum()) == 0
+    env.reset(demos.target_tensor)
+    state, done_step = env.step_many(demos.action_seq)
+    assert not bool(state.any()) and bool((done_step >= 0).all()) and int(done_step.max()) == R - 1
+    # linearity: target(a ++ b) == target(a) + target(b) (checksum of sums, no overflow at these R)
+    half = R // 2
+    ta = ops.gen_from_factors(demos.action_seq[:, :half].contiguous(), S)
+    tb = ops.gen_from_factors(demos.action_seq[:, half:].contiguous(), S)
+    assert torch.equal((ta.to(torch.int16) + tb.to(torch.int16)).to(torch.int8), demos.target_tensor)
+    # order independence of _take_actions (datasets.py:144-153 is a pure sum)
+    perm = torch.randperm(R, device=DEV)
+    env.reset(demos.target_tensor)
+    state, _ = env.step_many(demos.action_seq[:, perm].contiguous())
+    assert not bool(state.any())
+
+
+def test_sharded_env_equals_single_env():
+    S, B, R = 4, 1000, 7
+    demos = SyntheticDemos(R, B, 1, S, DEV, seed=4)
+    full = TensorGameEnv(B, S, DEV)
+    full.reset(demos.target_tensor)
+    full.step(demos.action_seq[:, 0])
+    parts = []
+    for rank in range(3):
+        lo, hi = mat_mul_amd.shard_range(B, rank, 3)
+        sd = SyntheticDemos(R, hi - lo, 1, S, DEV, seed=4, game_id_offset=lo)
+        assert torch.equal(sd.action_seq, demos.action_seq[lo:hi])
+        e = TensorGameEnv.sharded(B, S, rank, 3, DEV)
+        assert e.game_id_offset == lo and e.B == hi - lo
+        e.reset(sd.target_tensor)
+        e.step(sd.action_seq[:, 0])
+        parts.append(e.state)
+    assert torch.equal(torch.cat(parts), full.state)
+
+
+def test_graph_capture_of_steps():
+    """Launches go to the caller's stream, so K steps can be captured in one hipGraph."""
+    S, B, R = 4, 4096, 7
+    demos = SyntheticDemos(R, B, 1, S, DEV, seed=8)
+    env = TensorGameEnv(B, S, DEV)
+    env.reset(demos.target_tensor)
+    acts = [demos.action_seq[:, k].contiguous() for k in range(R)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        env.step(acts[0])          # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(side)
+    env.reset(demos.target_tensor)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for k in range(R):
+            env.step(acts[k])
+    env.reset(demos.target_tensor)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert bool(env.done.all()) and not bool(env.state.any())
