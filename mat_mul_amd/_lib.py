@@ -40,7 +40,25 @@ SIGNATURES = {
 }
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch-ROCm ships its own libamdhip64 (SONAME libamdhip64.so.7).  Two HIP runtimes in
+    one process do not share devices or streams (the second one reports "no ROCm-capable
+    device"), so torch's copy must be the one libtensorgame.so binds to: load it first; the
+    dynamic linker then satisfies our NEEDED libamdhip64.so.7 by SONAME."""
+    import torch  # noqa: F401  (maps torch/lib/libamdhip64.so)
+
+    cand = Path(torch.__file__).resolve().parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
+def _hip_runtimes_mapped():
+    with open("/proc/self/maps") as f:
+        return sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+
+
 def _load() -> C.CDLL:
+    _preload_torch_hip_runtime()
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP library is not built.  Run "
@@ -55,6 +73,9 @@ def _load() -> C.CDLL:
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
         fn.restype = C.c_char_p if name == "tg_last_error" else C.c_int
+    rts = _hip_runtimes_mapped()
+    if len(rts) > 1:
+        raise ImportError(f"two HIP runtimes are mapped ({rts}); libtensorgame.so must share PyTorch's")
     if lib.tg_abi_version() != TG_ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.tg_abi_version()} != {TG_ABI_VERSION}; rebuild it")
     return lib

@@ -234,7 +234,7 @@ int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, 
   if (B == 0) return TG_OK;
   if (!target_out || !actions_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
   const int64_t nvec = B * R * 3;
-  hipLaunchKernelGGL(tg::gen_tokens_kernel, dim3(grid_for((nvec + tg::kBlock - 1) / tg::kBlock)),
+  (void)hipGetLastError(); hipLaunchKernelGGL(tg::gen_tokens_kernel, dim3(grid_for((nvec + tg::kBlock - 1) / tg::kBlock)),
                      dim3(tg::kBlock), 0, static_cast<hipStream_t>(stream), actions_out, overflow, B, S, R,
                      D, shift, seed, game_id_offset, basis);
   if (int rc = launched(fn)) return rc;
@@ -250,7 +250,7 @@ int tg_sample_basis_i8(int8_t* basis_out, int8_t* lower_out, int8_t* upper_out, 
   if (int rc = make_dist(fn, thresholds, values, n_values, &D)) return rc;
   if (B == 0) return TG_OK;
   if (!basis_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
-  hipLaunchKernelGGL(tg::sample_basis_kernel, dim3(grid_for(3 * B)), dim3(tg::kBlock), 0,
+  (void)hipGetLastError(); hipLaunchKernelGGL(tg::sample_basis_kernel, dim3(grid_for(3 * B)), dim3(tg::kBlock), 0,
                      static_cast<hipStream_t>(stream), basis_out, lower_out, upper_out, B, S, D, seed,
                      game_id_offset);
   return launched(fn);
@@ -276,7 +276,7 @@ int tg_change_basis_i8(const int8_t* state_in, const int32_t* basis, int8_t* sta
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
       if (e != hipSuccess) return tg_internal_fail(TG_ERR_HIP, "%s: %s", fn, hipGetErrorString(e));    \
     }                                                                                                  \
-    hipLaunchKernelGGL(tg::change_basis_kernel<ST>, grid, block, lds, st, state_in, basis, state_out,  \
+    (void)hipGetLastError(); hipLaunchKernelGGL(tg::change_basis_kernel<ST>, grid, block, lds, st, state_in, basis, state_out,  \
                        overflow, B, S, game_stride_bytes);                                             \
   } while (0)
   switch (S) {

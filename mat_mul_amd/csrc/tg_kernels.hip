@@ -615,20 +615,20 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
   do {                                                                                          \
     const int64_t blocks = (B + Geo<S_, TS_>::GPB - 1) / Geo<S_, TS_>::GPB;                     \
     if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);              \
-    hipLaunchKernelGGL((team_kernel<S_, TS_, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a); \
+    (void)hipGetLastError(); hipLaunchKernelGGL((team_kernel<S_, TS_, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a); \
     return check_launch(fn);                                                                    \
   } while (0)
   if (al && a.S == 4 && aligned4(a.actions)) {
     const int64_t blocks = (B * 4 + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
-    hipLaunchKernelGGL((s4_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+    (void)hipGetLastError(); hipLaunchKernelGGL((s4_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
     return check_launch(fn);
   }
   if (al && a.S == 9) TG_TEAM(9, 64);
   if (al && a.S == 16) TG_TEAM(16, 64);
   if (al && a.S == 25) TG_TEAM(25, 256);
 #undef TG_TEAM
-  hipLaunchKernelGGL((slow_kernel<MODE>), dim3(capped_grid(B)), dim3(kBlock), 0, st, a);
+  (void)hipGetLastError(); hipLaunchKernelGGL((slow_kernel<MODE>), dim3(capped_grid(B)), dim3(kBlock), 0, st, a);
   return check_launch(fn);
 }
 
@@ -696,7 +696,7 @@ int tg_done_i8(const int8_t* state, uint8_t* done, int32_t* nnz, int64_t B, int 
   if (!state || !done) return fail(TG_ERR_INVALID, "tg_done_i8: null pointer");
   const int vec16 = aligned16(state) && game_stride_bytes % 16 == 0;
   const int64_t blocks = (B + 3) / 4;  // 4 wavefronts (games) per workgroup
-  hipLaunchKernelGGL(tg::done_kernel, dim3(capped_grid(blocks)), dim3(tg::kBlock), 0,
+  (void)hipGetLastError(); hipLaunchKernelGGL(tg::done_kernel, dim3(capped_grid(blocks)), dim3(tg::kBlock), 0,
                      static_cast<hipStream_t>(stream), state, done, nnz, B, S * S * S,
                      game_stride_bytes, vec16);
   return check_launch("tg_done_i8");
@@ -708,7 +708,7 @@ int tg_reset_matmul_i8(int8_t* state_out, int64_t B, int n, int64_t game_stride_
   if (int rc = validate_common("tg_reset_matmul_i8", B, n * n, game_stride_bytes)) return rc;
   if (B == 0) return TG_OK;
   if (!state_out) return fail(TG_ERR_INVALID, "tg_reset_matmul_i8: null pointer");
-  hipLaunchKernelGGL(tg::matmul_reset_kernel, dim3(capped_grid(B)), dim3(tg::kBlock), 0,
+  (void)hipGetLastError(); hipLaunchKernelGGL(tg::matmul_reset_kernel, dim3(capped_grid(B)), dim3(tg::kBlock), 0,
                      static_cast<hipStream_t>(stream), state_out, B, n, game_stride_bytes);
   return check_launch("tg_reset_matmul_i8");
 }
@@ -719,7 +719,7 @@ int tg_reset_broadcast_i8(const int8_t* start, int8_t* state_out, int64_t B, int
   if (B == 0) return TG_OK;
   if (!start || !state_out) return fail(TG_ERR_INVALID, "tg_reset_broadcast_i8: null pointer");
   const int vec16 = aligned16(start) && aligned16(state_out) && game_stride_bytes % 16 == 0;
-  hipLaunchKernelGGL(tg::broadcast_kernel, dim3(capped_grid(B)), dim3(tg::kBlock), 0,
+  (void)hipGetLastError(); hipLaunchKernelGGL(tg::broadcast_kernel, dim3(capped_grid(B)), dim3(tg::kBlock), 0,
                      static_cast<hipStream_t>(stream), start, state_out, B, S * S * S,
                      game_stride_bytes, vec16);
   return check_launch("tg_reset_broadcast_i8");

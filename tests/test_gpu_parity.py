@@ -180,12 +180,14 @@ def test_step_wide_tokens_and_overflow(S):
     st = rng.integers(-128, 128, size=(B, S, S, S)).astype(np.int8)
     ac = rng.integers(-3, 6, size=(B, 3 * S)).astype(np.int8)
     ac[::2] = rng.integers(0, 3, size=(len(ac[::2]), 3 * S))
+    st[::2] = np.clip(st[::2], -100, 100)  # these games cannot overflow for shift=1
     for shift in (1, 2, -1):
         want, want_done, want_ovf = O.step_i8(st, ac, shift=shift)
         ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
         out, done = ops.step(padded(st), dev(ac), overflow=ovf, shift=shift)
         assert np.array_equal(host(out), want) and np.array_equal(host(done), want_done)
-        assert np.array_equal(host(ovf), want_ovf) and want_ovf.any() and not want_ovf.all()
+        assert np.array_equal(host(ovf), want_ovf) and want_ovf.any()
+        assert shift != 1 or not want_ovf[::2].any()
         sticky = torch.ones(B, dtype=torch.uint8, device=DEV)           # never cleared by a call
         ops.step(padded(st), dev(ac), overflow=sticky, shift=shift)
         assert host(sticky).all()
