@@ -1,0 +1,22 @@
+#!/bin/bash
+# Profiling recipe for one round (run on the GPU box via gpurun from the repo root):
+#   bash profiles/run_profiles.sh r01
+# Writes raw rocprofv3 output under gpurun_out/prof_<tag>/ ; copy the *_stats.csv summaries into profiles/.
+set -o pipefail
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# 1. kernel trace + stats of the default bench command (hipGraph replay), no CPU leg
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_graph -o bench_graph -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_graph.json 2> $OUT/bench_graph.err || exit 1
+# 2. the same in eager mode (one ctypes launch per step)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_eager -o bench_eager -- python3 $R/bench.py --mode eager --no-cpu-baseline --no-also > $OUT/bench_eager.json 2> $OUT/bench_eager.err || exit 1
+# 3. HBM traffic counters, one pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass), eager, few steps
+for wl in "4 65536" "4 4194304" "16 8192" "16 131072"; do
+  set -- $wl
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_S$1_B$2_$ctr -o pmc -- python3 $R/bench.py --mode eager --steps 56 --warmup 14 --dim $1 --batch $2 --no-cpu-baseline --no-also > $OUT/pmc_S$1_B$2_$ctr.json 2> $OUT/pmc_S$1_B$2_$ctr.err || exit 1
+  done
+done
+echo profiles done

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (written by profiles/run_profiles.sh) into the
+small files committed under profiles/: kernel stats CSVs, the bench JSON lines of the profiled
+runs, and traffic_<tag>.json = per-launch HBM bytes of the step kernels from the PMC passes
+(FETCH_SIZE doubled on gfx950, WRITE_SIZE as is; /opt/skills/guides/MI355X_MICROARCH.md, HBM)."""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = Path(__file__).resolve().parent.parent
+src = root / "gpurun_out" / f"prof_{tag}"
+dst = root / "profiles"
+for name in ("bench_graph", "bench_eager"):
+    f = src / name / f"{name}_kernel_stats.csv"
+    if f.exists():
+        shutil.copy(f, dst / f"{tag}_{name}_kernel_stats.csv")
+    j = src / f"{name}.json"
+    if j.exists():
+        shutil.copy(j, dst / f"{tag}_{name}.json")
+
+traffic = {}
+for d in sorted(glob.glob(str(src / "pmc_*_SIZE"))):
+    parts = Path(d).name.split("_")  # pmc S4 B65536 FETCH SIZE
+    key, ctr = f"{parts[1]}_{parts[2]}", parts[3] + "_SIZE"
+    vals, durs = collections.defaultdict(list), collections.defaultdict(list)
+    for r in csv.DictReader(open(Path(d) / "pmc_counter_collection.csv")):
+        n = r["Kernel_Name"]
+        if "tg::" in n and ("<0>" in n or ", 0>" in n):  # the STEP kernels
+            vals[n].append(float(r["Counter_Value"]))
+            durs[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for n, v in vals.items():
+        e = traffic.setdefault(key, {"kernel": n.split("(")[0].replace("void ", ""), "launches": len(v)})
+        kb = sum(v) / len(v)
+        e[ctr + "_KB_per_launch"] = kb
+        e[ctr + "_avg_kernel_us_under_pmc"] = round(sum(durs[n]) / len(durs[n]) / 1e3, 2)
+for key, e in traffic.items():
+    if "FETCH_SIZE_KB_per_launch" in e and "WRITE_SIZE_KB_per_launch" in e:
+        e["hbm_bytes_per_launch"] = int((2 * e["FETCH_SIZE_KB_per_launch"] + e["WRITE_SIZE_KB_per_launch"]) * 1024)
+        S, B = int(key.split("_")[0][1:]), int(key.split("_")[1][1:])
+        e["algorithmic_bytes_per_launch"] = B * (2 * S ** 3 + 3 * S + 1)
+        e["traffic_over_algorithmic"] = round(e["hbm_bytes_per_launch"] / e["algorithmic_bytes_per_launch"], 4)
+json.dump(traffic, open(dst / f"traffic_{tag}.json", "w"), indent=1, sort_keys=True)
+print(json.dumps(traffic, indent=1, sort_keys=True))
