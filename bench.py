@@ -120,11 +120,25 @@ def time_steps(B, S, K, W, dev, mode, seed=0, gid0=0, R=None, sync=None):
     return {"wall_s": wall, "event_ms": ev0.elapsed_time(ev1), "ok": ok}
 
 
+def measured_traffic(B, S):
+    """HBM bytes per launch of this workload from the committed rocprofv3 PMC passes
+    (profiles/traffic_r*.json, written by profiles/summarize.py), newest round first; else None."""
+    for f in sorted((ROOT / "profiles").glob("traffic_r*.json"), reverse=True):
+        try:
+            e = json.loads(f.read_text()).get(f"S{S}_B{B}")
+        except (OSError, ValueError):
+            continue
+        if e and "hbm_bytes_per_launch" in e:
+            return e["hbm_bytes_per_launch"], f.name
+    return None, None
+
+
 def roofline(B, S, K, event_ms):
     per_launch_s = event_ms * 1e-3 / K
     achieved = B * bytes_step(S) / per_launch_s / 1e9
+    traffic, src = measured_traffic(B, S)
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "kernel": "tg::s4_kernel<STEP>" if S == 4 else f"tg::team_kernel<{S},...,STEP>",
             "bytes_per_launch": B * bytes_step(S), "avg_launch_us": round(per_launch_s * 1e6, 3)}
 
@@ -185,31 +199,21 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # control plane only: barrier + max of the elapsed time
-
-        dist.init_process_group("nccl", device_id=dev)
 
     import mat_mul_amd  # noqa: F401  (raises if libtensorgame.so is missing)
     from mat_mul_amd import shard_range
+    from mat_mul_amd.sharding import RankGroup
+
+    group = RankGroup("nccl", dev)  # control plane only: barrier + max of the elapsed time
 
     S = args.dim
     Bg = args.batch or {4: 65536, 16: 8192, 25: 4096, 9: 32768}.get(S, 4096)
     lo, hi = shard_range(Bg * world, rank, world)  # weak scaling: Bg games per GPU
     B = hi - lo
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-
-    res = time_steps(B, S, args.steps, args.warmup, dev, args.mode, seed=0, gid0=lo, sync=sync)
-    wall, ok = res["wall_s"], res["ok"]
-    if dist is not None:
-        t = torch.tensor([wall, 0.0 if ok else 1.0], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, ok = float(t[0]), float(t[1]) == 0.0
-    if not ok:
+    res = time_steps(B, S, args.steps, args.warmup, dev, args.mode, seed=0, gid0=lo, sync=group.barrier)
+    wall, bad = group.max_over_ranks(res["wall_s"], 0.0 if res["ok"] else 1.0)
+    if bad:
         raise SystemExit("bench self-check failed: the state did not return to its start after full cycles")
 
     if rank == 0:
@@ -239,8 +243,7 @@ def main():
                              "roofline": roofline(b2, s2, k2, r2["event_ms"])})
             out["also"] = also
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

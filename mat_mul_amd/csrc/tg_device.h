@@ -21,8 +21,13 @@ __device__ __forceinline__ uint32_t pack4(int n0, int n1, int n2, int n3) {
   return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
-// a*b + c with |a|,|b| < 2^23: one v_mad_i32_i24 (full-rate, unlike v_mul_lo_u32)
-__device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+// a*b for |a|,|b| < 2^23 as ONE full-rate v_mul_i32_i24.  hipcc (ROCm 7.2) lowers __mul24 of
+// values whose range it cannot see to the quarter-rate v_mul_lo_u32; the asm pins the opcode.
+__device__ __forceinline__ int mul24_pinned(int a, int b) {
+  int r;
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 // ---- team (sub-wave) reductions --------------------------------------------------------------
 

@@ -145,7 +145,7 @@ template <int S, bool SUB>
 __device__ __forceinline__ void rank1_16(int (&acc)[16], int i, int j, int l, const short* F, int& chg) {
   int ui = F[2 * S + i];
   if constexpr (SUB) ui = -ui;
-  int uv = __mul24(ui, F[j]);
+  int uv = mul24_pinned(ui, F[j]);
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const int p = __mul24(uv, F[S + l]);
@@ -159,7 +159,7 @@ __device__ __forceinline__ void rank1_16(int (&acc)[16], int i, int j, int l, co
         ui = F[2 * S + i];
         if constexpr (SUB) ui = -ui;
       }
-      uv = __mul24(ui, F[j]);
+      uv = mul24_pinned(ui, F[j]);
     }
   }
 }
@@ -404,7 +404,7 @@ __device__ __forceinline__ S4Factors s4_factors(const int* tok3, int q, int shif
 __device__ __forceinline__ void s4_rank1(int (&acc)[16], const S4Factors& f, int& chg) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int uv = __mul24(f.ui, f.v[j]);
+    const int uv = mul24_pinned(f.ui, f.v[j]);
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       const int p = __mul24(uv, f.w[l]);
@@ -416,80 +416,92 @@ __device__ __forceinline__ void s4_rank1(int (&acc)[16], const S4Factors& f, int
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
-  const int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  int64_t g = tid >> 2;
-  const int q = static_cast<int>(tid & 3);
-  const bool live = g < a.B;
-  if (!live) g = a.B - 1;
-  const int* tok = reinterpret_cast<const int*>(a.actions + g * a.nact * 12);
+  // Addressing: everything that depends on blockIdx is SCALAR 64-bit math (SALU); the per-lane
+  // part is a small 32-bit offset (host guarantees strides < 2^20).  At the BASELINE cfg2 shape
+  // (65 536 games, ~2.5 us per launch) vector 64-bit multiplies were 0.5 us of the launch.
+  constexpr int GPB = kBlock / 4;  // 64 games per workgroup
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * GPB;
+  const int nlive = static_cast<int>(min(static_cast<int64_t>(GPB), a.B - g0));
+  const int lg_raw = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const bool live = lg_raw < nlive;
+  const int lg = live ? lg_raw : nlive - 1;  // dead lanes shadow the last live game, stores predicated off
+  const int* tok = reinterpret_cast<const int*>(a.actions + g0 * a.nact * 12) + lg * a.nact * 3;
+  const int8_t* in_blk = a.in + g0 * a.in_stride;
+  const uint32_t in_off = __umul24(lg, static_cast<uint32_t>(a.in_stride)) + 16u * q;
   uint4 pk{0, 0, 0, 0};
-  if constexpr (MODE != GENF) pk = *reinterpret_cast<const uint4*>(a.in + g * a.in_stride + 16 * q);
+  if constexpr (MODE != GENF) pk = *reinterpret_cast<const uint4*>(in_blk + in_off);
   int ovf = 0;
 
-  if constexpr (MODE == STEP) {
-    const S4Factors f = s4_factors<true>(tok, q, a.shift);
-    int acc[16], chg = 0;
-    uint32_t nz = 0;
-    unpack16(pk, acc);
-    s4_rank1(acc, f, chg);
-    pk = pack16(acc, nz, ovf);
-    if (live) *reinterpret_cast<uint4*>(a.out + g * a.out_stride + 16 * q) = pk;
-    const bool any_nz = team_any<4>(nz != 0);
-    const bool any_ovf = team_any<4>((ovf & ~255) != 0);
-    if (q == 0 && live) {
-      a.done[g] = any_nz ? 0 : 1;
-      if (a.overflow && any_ovf) a.overflow[g] = 1;
-    }
-  } else if constexpr (MODE == MANY || MODE == GENF) {
-    int acc[16];
-    unpack16(pk, acc);
-    int done_step = -1;
-    int t0 = tok[0], t1 = tok[1], t2 = tok[2];
-    for (int k = 0; k < a.nact; ++k) {
-      const int cur[3] = {t0, t1, t2};
-      if (k + 1 < a.nact) {  // prefetch the next action's tokens
-        t0 = tok[3 * (k + 1)];
-        t1 = tok[3 * (k + 1) + 1];
-        t2 = tok[3 * (k + 1) + 2];
-      }
-      const S4Factors f = s4_factors<MODE != GENF>(cur, q, a.shift);
-      int chg = 0;
+  if constexpr (MODE == STEP || MODE == MANY || MODE == GENF) {
+    int8_t* out_blk = a.out + g0 * a.out_stride;
+    const uint32_t out_off = __umul24(lg, static_cast<uint32_t>(a.out_stride)) + 16u * q;
+    if constexpr (MODE == STEP) {
+      const S4Factors f = s4_factors<true>(tok, q, a.shift);
+      int acc[16], chg = 0;
+      uint32_t nz = 0;
+      unpack16(pk, acc);
       s4_rank1(acc, f, chg);
-      if constexpr (MODE == MANY) {
-        uint32_t nz = 0;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          nz |= static_cast<uint32_t>(acc[t]);
-          ovf |= acc[t] + 128;
+      pk = pack16(acc, nz, ovf);
+      if (live) *reinterpret_cast<uint4*>(out_blk + out_off) = pk;
+      const bool any_nz = team_any<4>(nz != 0);
+      const bool any_ovf = team_any<4>((ovf & ~255) != 0);
+      if (q == 0 && live) {
+        (a.done + g0)[lg] = any_nz ? 0 : 1;
+        if (a.overflow && any_ovf) (a.overflow + g0)[lg] = 1;
+      }
+    } else {
+      int acc[16];
+      unpack16(pk, acc);
+      int done_step = -1;
+      int t0 = tok[0], t1 = tok[1], t2 = tok[2];
+      for (int k = 0; k < a.nact; ++k) {
+        const int cur[3] = {t0, t1, t2};
+        if (k + 1 < a.nact) {  // prefetch the next action's tokens
+          t0 = tok[3 * (k + 1)];
+          t1 = tok[3 * (k + 1) + 1];
+          t2 = tok[3 * (k + 1) + 2];
         }
-        if (!team_any<4>((nz & 255) != 0) && done_step < 0) done_step = k;
+        const S4Factors f = s4_factors<MODE != GENF>(cur, q, a.shift);
+        int chg = 0;
+        s4_rank1(acc, f, chg);
+        if constexpr (MODE == MANY) {
+          uint32_t nz = 0;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            nz |= static_cast<uint32_t>(acc[t]);
+            ovf |= acc[t] + 128;
+          }
+          if (!team_any<4>((nz & 255) != 0) && done_step < 0) done_step = k;
+        }
+      }
+      uint32_t nz = 0;
+      pk = pack16(acc, nz, ovf);
+      if (live) *reinterpret_cast<uint4*>(out_blk + out_off) = pk;
+      const bool any_ovf = team_any<4>((ovf & ~255) != 0);
+      if (q == 0 && live) {
+        if constexpr (MODE == MANY) (a.done_step + g0)[lg] = done_step;
+        if (a.overflow && any_ovf) (a.overflow + g0)[lg] = 1;
       }
     }
-    uint32_t nz = 0;
-    pk = pack16(acc, nz, ovf);
-    if (live) *reinterpret_cast<uint4*>(a.out + g * a.out_stride + 16 * q) = pk;
-    const bool any_ovf = team_any<4>((ovf & ~255) != 0);
-    if (q == 0 && live) {
-      if constexpr (MODE == MANY) a.done_step[g] = done_step;
-      if (a.overflow && any_ovf) a.overflow[g] = 1;
-    }
-  } else {  // EXPAND
+  } else {  // EXPAND: child (g, k) lives at out + (g*nact + k) * out_stride
+    int8_t* out_blk = a.out + g0 * a.nact * a.out_stride;
+    const int64_t c0 = g0 * a.nact;
     for (int k = 0; k < a.nact; ++k) {
       const S4Factors f = s4_factors<true>(tok + 3 * k, q, a.shift);
-      const int64_t child = g * a.nact + k;
+      const uint32_t child = static_cast<uint32_t>(lg) * static_cast<uint32_t>(a.nact) + k;  // < 64 * 4096
       int acc[16], chg = 0, covf = 0;
       uint32_t nz = 0;
       unpack16(pk, acc);
       s4_rank1(acc, f, chg);
       const uint4 o = pack16(acc, nz, covf);
-      if (live) *reinterpret_cast<uint4*>(a.out + child * a.out_stride + 16 * q) = o;
+      if (live) *reinterpret_cast<uint4*>(out_blk + static_cast<int64_t>(child) * a.out_stride + 16 * q) = o;
       const bool any_nz = team_any<4>(nz != 0);
       const bool any_chg = team_any<4>(chg != 0);
       const bool any_ovf = team_any<4>((covf & ~255) != 0);
       if (q == 0 && live) {
-        a.done[child] = any_nz ? 0 : 1;
-        if (a.changed) a.changed[child] = any_chg ? 1 : 0;
-        if (a.overflow && any_ovf) a.overflow[child] = 1;
+        (a.done + c0)[child] = any_nz ? 0 : 1;
+        if (a.changed) (a.changed + c0)[child] = any_chg ? 1 : 0;
+        if (a.overflow && any_ovf) (a.overflow + c0)[child] = 1;
       }
     }
   }
@@ -618,7 +630,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
     (void)hipGetLastError(); hipLaunchKernelGGL((team_kernel<S_, TS_, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a); \
     return check_launch(fn);                                                                    \
   } while (0)
-  if (al && a.S == 4 && aligned4(a.actions)) {
+  if (al && a.S == 4 && aligned4(a.actions) && a.in_stride < (1 << 20) && a.out_stride < (1 << 20)) {
     const int64_t blocks = (B * 4 + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
     (void)hipGetLastError(); hipLaunchKernelGGL((s4_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);

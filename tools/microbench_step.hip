@@ -1,0 +1,221 @@
+// Standalone microbenchmark (no torch): what bounds ONE tg_step launch at the BASELINE cfg2 shape
+// (S=4, 65 536 games = 4 MiB of state)?  Measures, as hipGraph replays of N chained launches:
+//   empty      -- a kernel with the same grid that does nothing (launch/boundary floor)
+//   copy       -- 16 B load + 16 B store per lane + done byte (memory path floor)
+//   variants of the step kernel (grid shape, games per lane, arithmetic form)
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/microbench_step.hip -o tools/microbench_step
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                       \
+  do {                                                                              \
+    hipError_t e_ = (x);                                                            \
+    if (e_ != hipSuccess) {                                                         \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));     \
+      exit(1);                                                                      \
+    }                                                                               \
+  } while (0)
+
+__device__ __forceinline__ int sbyte(uint32_t w, int t) { return __builtin_amdgcn_sbfe((int)w, 8 * t, 8); }
+__device__ __forceinline__ uint32_t pack4(int n0, int n1, int n2, int n3) {
+  uint32_t lo = __builtin_amdgcn_perm((uint32_t)n1, (uint32_t)n0, 0x0c0c0400u);
+  uint32_t hi = __builtin_amdgcn_perm((uint32_t)n3, (uint32_t)n2, 0x0c0c0400u);
+  return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_empty(const uint4* in, uint4* out, const int* tok, uint8_t* done, int B) {}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_copy(const uint4* in, uint4* out, const int* tok, uint8_t* done, int B) {
+  const int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t < 4 * B) {
+    uint4 q = in[t];
+    out[t] = q;
+    if ((t & 3) == 0) done[t >> 2] = (q.x | q.y | q.z | q.w) == 0;
+  }
+}
+
+// reference form: 32-bit per element, as in tg_kernels.hip s4_kernel<STEP> but 32-bit indexing
+template <int BLOCK, int GPL>  // GPL = games handled per 4-lane team (chunks per lane)
+__global__ __launch_bounds__(BLOCK) void k_step32(const uint4* in, uint4* out, const int* tok, uint8_t* done, int B) {
+  const int t0 = (blockIdx.x * BLOCK + threadIdx.x);
+  const int q = t0 & 3;
+  const int team = t0 >> 2;
+  const int nteams = (gridDim.x * BLOCK) >> 2;
+  uint4 pk[GPL];
+  int tk[GPL][3];
+#pragma unroll
+  for (int n = 0; n < GPL; ++n) {
+    int g = team + n * nteams;
+    if (g >= B) g = B - 1;
+    pk[n] = in[g * 4 + q];
+    tk[n][0] = tok[g * 3];
+    tk[n][1] = tok[g * 3 + 1];
+    tk[n][2] = tok[g * 3 + 2];
+  }
+#pragma unroll
+  for (int n = 0; n < GPL; ++n) {
+    const int g = team + n * nteams;
+    const int ui = -(__builtin_amdgcn_sbfe(tk[n][0], 8 * q, 8) - 1);
+    int v[4], w[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      v[t] = sbyte(tk[n][1], t) - 1;
+      w[t] = sbyte(tk[n][2], t) - 1;
+    }
+    const uint32_t wd[4] = {pk[n].x, pk[n].y, pk[n].z, pk[n].w};
+    uint32_t o[4], nz = 0;
+    int ovf = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int uv = __mul24(ui, v[j]);
+      int r[4];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        r[l] = __mul24(uv, w[l]) + sbyte(wd[j], l);
+        ovf |= r[l] + 128;
+      }
+      o[j] = pack4(r[0], r[1], r[2], r[3]);
+      nz |= o[j];
+    }
+    const uint64_t m = __ballot(nz != 0);
+    const int lane = threadIdx.x & 63;
+    const bool any = ((m >> (lane & ~3)) & 0xf) != 0;
+    if (g < B) {
+      out[g * 4 + q] = uint4{o[0], o[1], o[2], o[3]};
+      if (q == 0) done[g] = !any;
+    }
+    if (ovf & ~255) done[0] = 2;  // stand-in for the rare overflow store
+  }
+}
+
+// biased form: state bytes ^ 0x80 are unsigned, n+128 is computed directly so the range check is one OR
+template <int BLOCK, int GPL>
+__global__ __launch_bounds__(BLOCK) void k_stepb(const uint4* in, uint4* out, const int* tok, uint8_t* done, int B) {
+  const int t0 = (blockIdx.x * BLOCK + threadIdx.x);
+  const int q = t0 & 3;
+  const int team = t0 >> 2;
+  const int nteams = (gridDim.x * BLOCK) >> 2;
+  uint4 pk[GPL];
+  int tk[GPL][3];
+#pragma unroll
+  for (int n = 0; n < GPL; ++n) {
+    int g = team + n * nteams;
+    if (g >= B) g = B - 1;
+    pk[n] = in[g * 4 + q];
+    tk[n][0] = tok[g * 3];
+    tk[n][1] = tok[g * 3 + 1];
+    tk[n][2] = tok[g * 3 + 2];
+  }
+#pragma unroll
+  for (int n = 0; n < GPL; ++n) {
+    const int g = team + n * nteams;
+    const int ui = -(__builtin_amdgcn_sbfe(tk[n][0], 8 * q, 8) - 1);
+    int v[4], w[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      v[t] = sbyte(tk[n][1], t) - 1;
+      w[t] = sbyte(tk[n][2], t) - 1;
+    }
+    const uint32_t wd[4] = {pk[n].x ^ 0x80808080u, pk[n].y ^ 0x80808080u, pk[n].z ^ 0x80808080u,
+                            pk[n].w ^ 0x80808080u};
+    uint32_t o[4], nz = 0;
+    uint32_t ovf = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int uv = __mul24(ui, v[j]);
+      int r[4];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        r[l] = __mul24(uv, w[l]) + (int)__builtin_amdgcn_ubfe(wd[j], 8 * l, 8);
+        ovf |= (uint32_t)r[l];
+      }
+      o[j] = pack4(r[0], r[1], r[2], r[3]) ^ 0x80808080u;
+      nz |= o[j];
+    }
+    const uint64_t m = __ballot(nz != 0);
+    const int lane = threadIdx.x & 63;
+    const bool any = ((m >> (lane & ~3)) & 0xf) != 0;
+    if (g < B) {
+      out[g * 4 + q] = uint4{o[0], o[1], o[2], o[3]};
+      if (q == 0) done[g] = !any;
+    }
+    if (ovf & ~255u) done[0] = 2;
+  }
+}
+
+struct Variant {
+  const char* name;
+  void (*kern)(const uint4*, uint4*, const int*, uint8_t*, int);
+  int block, gpl;
+};
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 65536;
+  const int N = argc > 2 ? atoi(argv[2]) : 2000;
+  uint4* st;
+  int* tok;
+  uint8_t* done;
+  CK(hipMalloc(&st, (size_t)B * 64));
+  CK(hipMalloc(&tok, (size_t)B * 12));
+  CK(hipMalloc(&done, B));
+  std::vector<uint8_t> hs((size_t)B * 64), ht((size_t)B * 12);
+  for (auto& x : hs) x = (uint8_t)((rand() % 5) - 2);
+  for (size_t i = 0; i < ht.size(); ++i) ht[i] = (i / 12) % 2 ? 1 : (uint8_t)(rand() % 3);  // half the games get a no-op
+  CK(hipMemcpy(tok, ht.data(), ht.size(), hipMemcpyHostToDevice));
+  hipStream_t s;
+  CK(hipStreamCreate(&s));
+  std::vector<Variant> vs = {
+      {"empty  256thr x1", k_empty<256>, 256, 1},   {"empty 1024thr x1", k_empty<1024>, 1024, 1},
+      {"copy   256thr x1", k_copy<256>, 256, 1},    {"copy  1024thr x1", k_copy<1024>, 1024, 1},
+      {"step32 256thr x1", k_step32<256, 1>, 256, 1}, {"step32 256thr x2", k_step32<256, 2>, 256, 2},
+      {"step32 256thr x4", k_step32<256, 4>, 256, 4}, {"step32 512thr x1", k_step32<512, 1>, 512, 1},
+      {"step32 1024thr x1", k_step32<1024, 1>, 1024, 1}, {"step32 1024thr x2", k_step32<1024, 2>, 1024, 2},
+      {"step32 1024thr x4", k_step32<1024, 4>, 1024, 4},
+      {"stepb  256thr x1", k_stepb<256, 1>, 256, 1}, {"stepb  256thr x2", k_stepb<256, 2>, 256, 2},
+      {"stepb  512thr x2", k_stepb<512, 2>, 512, 2}, {"stepb 1024thr x1", k_stepb<1024, 1>, 1024, 1},
+      {"stepb 1024thr x2", k_stepb<1024, 2>, 1024, 2}, {"stepb 1024thr x4", k_stepb<1024, 4>, 1024, 4},
+  };
+  printf("B=%d games, %d launches per graph; algorithmic bytes per launch = %.2f MB\n", B, N, B * 141 / 1e6);
+  for (int rep = 0; rep < 2; ++rep)
+    for (auto& v : vs) {
+      CK(hipMemcpy(st, hs.data(), hs.size(), hipMemcpyHostToDevice));
+      const int threads = 4 * B / v.gpl;
+      const int grid = (threads + v.block - 1) / v.block;
+      hipGraph_t g;
+      hipGraphExec_t ge;
+      CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+      for (int i = 0; i < N; ++i) hipLaunchKernelGGL(v.kern, dim3(grid), dim3(v.block), 0, s, st, st, tok, done, B);
+      CK(hipStreamEndCapture(s, &g));
+      CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      CK(hipGraphLaunch(ge, s));
+      CK(hipStreamSynchronize(s));
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      CK(hipEventRecord(e0, s));
+      CK(hipGraphLaunch(ge, s));
+      CK(hipEventRecord(e1, s));
+      CK(hipStreamSynchronize(s));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      // eager launches for comparison
+      CK(hipEventRecord(e0, s));
+      for (int i = 0; i < N; ++i) hipLaunchKernelGGL(v.kern, dim3(grid), dim3(v.block), 0, s, st, st, tok, done, B);
+      CK(hipEventRecord(e1, s));
+      CK(hipStreamSynchronize(s));
+      float ms2;
+      CK(hipEventElapsedTime(&ms2, e0, e1));
+      if (rep == 1)
+        printf("%-18s grid=%5d  graph %.3f us/launch (%.0f GB/s alg)   eager %.3f us/launch\n", v.name, grid,
+               ms * 1e3 / N, B * 141.0 / (ms * 1e-3 / N) / 1e9, ms2 * 1e3 / N);
+      CK(hipGraphExecDestroy(ge));
+      CK(hipGraphDestroy(g));
+    }
+  return 0;
+}
