@@ -53,9 +53,11 @@ struct U4 {
 __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-    c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    // one v_mad_u64_u32 per product (hi and lo together) instead of v_mul_hi_u32 + v_mul_lo_u32
+    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c.x;
+    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c.z;
+    c = U4{static_cast<uint32_t>(p1 >> 32) ^ c.y ^ k0, static_cast<uint32_t>(p1),
+           static_cast<uint32_t>(p0 >> 32) ^ c.w ^ k1, static_cast<uint32_t>(p0)};
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }

@@ -24,6 +24,10 @@ struct Dist {
 };
 
 __device__ __forceinline__ int draw_value(uint32_t d, const Dist& D) {
+  if (D.nv == 3) {  // the reference's vocabulary (-1,0,1): two compares, two selects (wave-uniform branch)
+    const int v = d >= D.thr[0] ? D.val[1] : D.val[0];
+    return d >= D.thr[1] ? D.val[2] : v;
+  }
   int idx = 0;
 #pragma unroll
   for (int t = 0; t < TG_MAX_VALUES - 1; ++t) idx += (t < D.nv - 1) && (d >= D.thr[t]);
@@ -38,56 +42,93 @@ constexpr uint32_t kMaxAttempts = 1u << 16;
 
 // One thread per factor vector (game b, term r, x in {u,v,w}).  Counter = (gid_lo, gid_hi,
 // 3r+x, attempt<<8 | block), key = seed: identical to oracle/tensor_game.py::_draw_vector.
+// ST > 0: S is a compile-time constant, the vector lives in registers.  The 256 vectors of a
+// workgroup are contiguous in actions_out, so they are assembled in LDS and written with 16-byte
+// stores (vec16) instead of S-strided byte stores.
+template <int ST>
 __global__ __launch_bounds__(kBlock) void gen_tokens_kernel(int8_t* actions_out, uint8_t* overflow, int64_t B,
-                                                            int S, int R, Dist D, int shift, uint64_t seed,
-                                                            uint64_t gid0, const int8_t* basis) {
+                                                            int Srt, int R, Dist D, int shift, uint64_t seed,
+                                                            uint64_t gid0, const int8_t* basis, int vec16) {
+  constexpr int SMAX = ST ? ST : TG_MAX_S;
+  constexpr int NBLK = (SMAX + 3) / 4;
+  __shared__ __attribute__((aligned(16))) int8_t stage[kBlock * SMAX];
+  const int S = ST ? ST : Srt;
   const int64_t nvec = B * R * 3;
   const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
-  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < nvec;
-       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const int64_t b = idx / (3 * R);
-    const int sub = static_cast<int>(idx - b * 3 * R);  // 3r + x
-    const int x = sub % 3;
-    const uint64_t gid = gid0 + static_cast<uint64_t>(b);
-    int f[TG_MAX_S];
-    const int nblk = (S + 3) >> 2;
-    for (uint32_t attempt = 0;; ++attempt) {
-      bool any = false;
-      for (int q = 0; q < nblk; ++q) {
-        const U4 o = philox4x32_10(U4{static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
-                                      static_cast<uint32_t>(sub), (attempt << 8) | static_cast<uint32_t>(q)},
-                                   k0, k1);
-        const uint32_t d[4] = {o.x, o.y, o.z, o.w};
+  const int64_t nround = (nvec + static_cast<int64_t>(gridDim.x) * kBlock - 1) / (static_cast<int64_t>(gridDim.x) * kBlock);
+  for (int64_t it = 0; it < nround; ++it) {
+    const int64_t base = (it * gridDim.x + blockIdx.x) * kBlock;  // first vector of this workgroup
+    const int64_t idx = base + threadIdx.x;
+    const bool live = idx < nvec;
+    int f[SMAX];
+    int bad = 0;
+    int64_t b = 0;
+    if (live) {
+      // 64-bit division once per workgroup on the scalar unit, 32-bit per lane
+      const int64_t b0 = base / (3 * R);
+      const uint32_t within = static_cast<uint32_t>(base - b0 * 3 * R) + threadIdx.x;
+      const uint32_t db = within / static_cast<uint32_t>(3 * R);
+      b = b0 + db;
+      const int sub = static_cast<int>(within - db * static_cast<uint32_t>(3 * R));  // 3r + x
+      const uint64_t gid = gid0 + static_cast<uint64_t>(b);
+      for (uint32_t attempt = 0;; ++attempt) {
+        bool any = false;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int s = 4 * q + t;
-          if (s < S) {
-            f[s] = draw_value(d[t], D);
-            any |= f[s] != 0;
+        for (int q = 0; q < NBLK; ++q) {
+          if (4 * q < S) {
+            const U4 o = philox4x32_10(U4{static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
+                                          static_cast<uint32_t>(sub), (attempt << 8) | static_cast<uint32_t>(q)},
+                                       k0, k1);
+            const uint32_t d[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int e = 4 * q + t;
+              if (e < SMAX) {
+                f[e] = (e < S) ? draw_value(d[t], D) : 0;
+                any |= f[e] != 0;
+              }
+            }
           }
         }
+        if (any || attempt + 1 >= kMaxAttempts) break;
       }
-      if (any || attempt + 1 >= kMaxAttempts) break;
+      int8_t* dst = stage + threadIdx.x * S;
+      if (basis) {
+        const int x = sub % 3;
+        const int8_t* M = basis + (b * 3 + x) * S * S;
+        for (int a = 0; a < S; ++a) {
+          int acc = 0;
+#pragma unroll
+          for (int i = 0; i < SMAX; ++i)
+            if (i < S) acc += M[a * S + i] * f[i];
+          const int tokv = acc + shift;
+          bad |= tokv + 128;
+          dst[a] = static_cast<int8_t>(tokv);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < SMAX; ++e)
+          if (e < S) {
+            const int tokv = f[e] + shift;
+            bad |= tokv + 128;
+            dst[e] = static_cast<int8_t>(tokv);
+          }
+      }
+      if (overflow && (bad & ~255)) overflow[b] = 1;
     }
-    int8_t* dst = actions_out + idx * S;  // ((b*R + r)*3 + x)*S
-    int bad = 0;
-    if (basis) {
-      const int8_t* M = basis + (b * 3 + x) * S * S;
-      for (int a = 0; a < S; ++a) {
-        int acc = 0;
-        for (int i = 0; i < S; ++i) acc += M[a * S + i] * f[i];
-        const int tokv = acc + shift;
-        bad |= tokv + 128;
-        dst[a] = static_cast<int8_t>(tokv);
-      }
-    } else {
-      for (int s = 0; s < S; ++s) {
-        const int tokv = f[s] + shift;
-        bad |= tokv + 128;
-        dst[s] = static_cast<int8_t>(tokv);
-      }
+    __syncthreads();
+    // the workgroup's vectors are the contiguous bytes [base*S, base*S + nlive*S) of actions_out
+    const int64_t nlive = min(static_cast<int64_t>(kBlock), nvec - base);
+    const int nbytes = nlive > 0 ? static_cast<int>(nlive) * S : 0;
+    int8_t* out = actions_out + base * S;
+    int body = 0;
+    if (vec16 && ((kBlock * S) % 16 == 0)) {
+      body = nbytes & ~15;
+      for (int o = 16 * threadIdx.x; o < body; o += 16 * kBlock)
+        *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(stage + o);
     }
-    if (overflow && (bad & ~255)) overflow[b] = 1;
+    for (int o = body + threadIdx.x; o < nbytes; o += kBlock) out[o] = stage[o];
+    __syncthreads();
   }
 }
 
@@ -234,9 +275,21 @@ int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, 
   if (B == 0) return TG_OK;
   if (!target_out || !actions_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
   const int64_t nvec = B * R * 3;
-  (void)hipGetLastError(); hipLaunchKernelGGL(tg::gen_tokens_kernel, dim3(grid_for((nvec + tg::kBlock - 1) / tg::kBlock)),
-                     dim3(tg::kBlock), 0, static_cast<hipStream_t>(stream), actions_out, overflow, B, S, R,
-                     D, shift, seed, game_id_offset, basis);
+  const int vec16 = (reinterpret_cast<uintptr_t>(actions_out) & 15) == 0;
+  const dim3 grid(grid_for((nvec + tg::kBlock - 1) / tg::kBlock > 16384 ? 16384 : (nvec + tg::kBlock - 1) / tg::kBlock));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  (void)hipGetLastError();
+#define TG_GT(ST)                                                                                     \
+  hipLaunchKernelGGL(tg::gen_tokens_kernel<ST>, grid, dim3(tg::kBlock), 0, st, actions_out, overflow, \
+                     B, S, R, D, shift, seed, game_id_offset, basis, vec16)
+  switch (S) {
+    case 4: TG_GT(4); break;
+    case 9: TG_GT(9); break;
+    case 16: TG_GT(16); break;
+    case 25: TG_GT(25); break;
+    default: TG_GT(0); break;
+  }
+#undef TG_GT
   if (int rc = launched(fn)) return rc;
   return tg_gen_from_factors_i8(actions_out, target_out, overflow, B, S, R, game_stride_bytes, shift, stream);
 }

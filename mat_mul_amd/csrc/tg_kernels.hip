@@ -14,6 +14,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/tensor_game.h"
@@ -44,80 +45,85 @@ struct ApplyArgs {
 // =============================================================================================
 // slow path: any S, any alignment.  One workgroup per game, one byte per thread-iteration.
 // =============================================================================================
+// One game (index b) by the whole workgroup.  nzf: TG_MAX_ACTIONS bytes of LDS (MANY only).
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void slow_kernel(ApplyArgs a) {
-  __shared__ uint8_t nzf[TG_MAX_ACTIONS];
+__device__ __forceinline__ void slow_game(const ApplyArgs& a, int64_t b, uint8_t* nzf) {
   const int S = a.S, S2 = S * S, N = S2 * S, A3 = 3 * S;
   const int tid = threadIdx.x;
-  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
-    const int8_t* tok = a.actions + b * a.nact * A3;
-    if constexpr (MODE == EXPAND) {
-      const int8_t* src = a.in + b * a.in_stride;
-      for (int c = 0; c < a.nact; ++c) {
-        const int8_t* t = tok + c * A3;
-        int8_t* dst = a.out + (b * a.nact + c) * a.out_stride;
-        int nz = 0, chg = 0, ovf = 0;
-        for (int e = tid; e < N; e += kBlock) {
-          const int i = e / S2, r = e - i * S2, j = r / S, l = r - j * S;
-          const int p = (t[i] - a.shift) * (t[S + j] - a.shift) * (t[2 * S + l] - a.shift);
-          const int n = src[e] - p;
-          dst[e] = static_cast<int8_t>(n);
-          nz |= n & 255;
-          chg |= p;
-          ovf |= (n + 128);
-        }
-        nz = __syncthreads_or(nz);
-        chg = __syncthreads_or(chg);
-        ovf = __syncthreads_or(ovf & ~255);
-        if (tid == 0) {
-          a.done[b * a.nact + c] = nz ? 0 : 1;
-          if (a.changed) a.changed[b * a.nact + c] = chg ? 1 : 0;
-          if (a.overflow && ovf) a.overflow[b * a.nact + c] = 1;
-        }
-      }
-    } else {
-      if constexpr (MODE == MANY) {
-        for (int k = tid; k < a.nact; k += kBlock) nzf[k] = 0;
-        __syncthreads();
-      }
-      const int8_t* src = (MODE == GENF) ? nullptr : a.in + b * a.in_stride;
-      int8_t* dst = a.out + b * a.out_stride;
-      int nz = 0, ovf = 0;
+  const int8_t* tok = a.actions + b * a.nact * A3;
+  if constexpr (MODE == EXPAND) {
+    const int8_t* src = a.in + b * a.in_stride;
+    for (int c = 0; c < a.nact; ++c) {
+      const int8_t* t = tok + c * A3;
+      int8_t* dst = a.out + (b * a.nact + c) * a.out_stride;
+      int nz = 0, chg = 0, ovf = 0;
       for (int e = tid; e < N; e += kBlock) {
         const int i = e / S2, r = e - i * S2, j = r / S, l = r - j * S;
-        int acc = (MODE == GENF) ? 0 : src[e];
-        for (int k = 0; k < a.nact; ++k) {
-          const int8_t* t = tok + k * A3;
-          const int p = (t[i] - a.shift) * (t[S + j] - a.shift) * (t[2 * S + l] - a.shift);
-          if constexpr (MODE == GENF) {
-            acc += p;
-          } else {
-            acc -= p;
-            ovf |= (acc + 128);
-            if constexpr (MODE == MANY) {
-              if (acc & 255) nzf[k] = 1;
-            }
-          }
-        }
-        if constexpr (MODE == GENF) ovf |= (acc + 128);
-        dst[e] = static_cast<int8_t>(acc);
-        nz |= acc & 255;
+        const int p = (t[i] - a.shift) * (t[S + j] - a.shift) * (t[2 * S + l] - a.shift);
+        const int n = src[e] - p;
+        dst[e] = static_cast<int8_t>(n);
+        nz |= n & 255;
+        chg |= p;
+        ovf |= (n + 128);
       }
       nz = __syncthreads_or(nz);
+      chg = __syncthreads_or(chg);
       ovf = __syncthreads_or(ovf & ~255);
       if (tid == 0) {
-        if constexpr (MODE == STEP) a.done[b] = nz ? 0 : 1;
-        if constexpr (MODE == MANY) {
-          int first = -1;
-          for (int k = 0; k < a.nact; ++k)
-            if (!nzf[k]) { first = k; break; }
-          a.done_step[b] = first;
-        }
-        if (a.overflow && ovf) a.overflow[b] = 1;
+        a.done[b * a.nact + c] = nz ? 0 : 1;
+        if (a.changed) a.changed[b * a.nact + c] = chg ? 1 : 0;
+        if (a.overflow && ovf) a.overflow[b * a.nact + c] = 1;
       }
+    }
+  } else {
+    if constexpr (MODE == MANY) {
+      __syncthreads();
+      for (int k = tid; k < a.nact; k += kBlock) nzf[k] = 0;
       __syncthreads();
     }
+    const int8_t* src = (MODE == GENF) ? nullptr : a.in + b * a.in_stride;
+    int8_t* dst = a.out + b * a.out_stride;
+    int nz = 0, ovf = 0;
+    for (int e = tid; e < N; e += kBlock) {
+      const int i = e / S2, r = e - i * S2, j = r / S, l = r - j * S;
+      int acc = (MODE == GENF) ? 0 : src[e];
+      for (int k = 0; k < a.nact; ++k) {
+        const int8_t* t = tok + k * A3;
+        const int p = (t[i] - a.shift) * (t[S + j] - a.shift) * (t[2 * S + l] - a.shift);
+        if constexpr (MODE == GENF) {
+          acc += p;
+        } else {
+          acc -= p;
+          ovf |= (acc + 128);
+          if constexpr (MODE == MANY) {
+            if (acc & 255) nzf[k] = 1;
+          }
+        }
+      }
+      if constexpr (MODE == GENF) ovf |= (acc + 128);
+      dst[e] = static_cast<int8_t>(acc);
+      nz |= acc & 255;
+    }
+    nz = __syncthreads_or(nz);
+    ovf = __syncthreads_or(ovf & ~255);
+    if (tid == 0) {
+      if constexpr (MODE == STEP) a.done[b] = nz ? 0 : 1;
+      if constexpr (MODE == MANY) {
+        int first = -1;
+        for (int k = 0; k < a.nact; ++k)
+          if (!nzf[k]) { first = k; break; }
+        a.done_step[b] = first;
+      }
+      if (a.overflow && ovf) a.overflow[b] = 1;
+    }
+    __syncthreads();
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void slow_kernel(ApplyArgs a) {
+  __shared__ uint8_t nzf[MODE == MANY ? TG_MAX_ACTIONS : 4];
+  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) slow_game<MODE>(a, b, nzf);
 }
 
 // =============================================================================================
@@ -207,12 +213,12 @@ __device__ __forceinline__ void store_chunk(int8_t* p, const uint4& q, bool tail
   *reinterpret_cast<uint4*>(p) = q;
 }
 
+// The exact 32-bit form: any factor magnitude.  Body of team_kernel, and the fallback of the
+// packed-int16 kernels (tg_packed.h) for games whose factors are too large for 16-bit sums.
 template <int S, int TS, int MODE>
-__global__ __launch_bounds__(kBlock) void team_kernel(ApplyArgs a) {
+__device__ __forceinline__ void team_body_i32(const ApplyArgs& a, short* lds, uint8_t* nzf) {
   using G = Geo<S, TS>;
   constexpr bool SUB = (MODE != GENF);
-  __shared__ short lds[G::LDS_BYTES / 2];
-  __shared__ uint8_t nzf[(MODE == MANY && TS == 256) ? TG_MAX_ACTIONS : 4];
 
   const int tid = threadIdx.x;
   const int team = tid / TS, lt = tid % TS;
@@ -378,6 +384,15 @@ __global__ __launch_bounds__(kBlock) void team_kernel(ApplyArgs a) {
   }
 }
 
+template <int S, int TS, int MODE>
+__global__ __launch_bounds__(kBlock) void team_kernel(ApplyArgs a) {
+  __shared__ short lds[Geo<S, TS>::LDS_BYTES / 2];
+  __shared__ uint8_t nzf[(MODE == MANY && TS == 256) ? TG_MAX_ACTIONS : 4];
+  team_body_i32<S, TS, MODE>(a, lds, nzf);
+}
+
+#include "tg_packed.h"
+
 // =============================================================================================
 // S = 4 in registers: 4 lanes per game, lane q owns slice i = q (16 bytes = one dwordx4).
 // Tokens: 12 bytes per action = three dwords (u | v | w), read by every lane of the game.
@@ -511,67 +526,81 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
 // terminal check / nnz, and reset
 // =============================================================================================
 
-// One wavefront per game, grid-stride over games; 16-byte loads when the layout allows it.
+// Terminal check + nnz.  A team of `lpg` consecutive lanes (power of two <= 64, chosen on the host
+// so that small games do not waste a wavefront: S=4 -> 4 lanes, 16 games per wavefront) owns one
+// game; 16-byte loads when the layout allows it (vec16), bytes otherwise.
+__device__ __forceinline__ int count_nonzero_bytes(uint32_t x) {
+  x |= x >> 4;
+  x |= x >> 2;
+  x |= x >> 1;
+  return __popc(x & 0x01010101u);  // each byte folded onto its low bit
+}
+
 __global__ __launch_bounds__(kBlock) void done_kernel(const int8_t* state, uint8_t* done, int32_t* nnz,
-                                                      int64_t B, int N, int64_t stride, int vec16) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
-  const int64_t nwave = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
-  for (int64_t g = wave; g < B; g += nwave) {
-    const int8_t* p = state + g * stride;
-    int cnt = 0;
-    int body = 0;
+                                                      int64_t B, int N, int64_t stride, int vec16, int lpg) {
+  const int lt = threadIdx.x & (lpg - 1);
+  const int64_t team = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / lpg;
+  const int64_t nteam = (static_cast<int64_t>(gridDim.x) * kBlock) / lpg;
+  const int64_t rounds = (B + nteam - 1) / nteam;  // every lane runs the same number of rounds (shuffles)
+  for (int64_t it = 0; it < rounds; ++it) {
+    const int64_t g = team + it * nteam;
+    const bool live = g < B;
+    const int8_t* p = state + (live ? g : B - 1) * stride;
+    int cnt = 0, body = 0;
     if (vec16) {
       body = N & ~15;
-      for (int e = 16 * lane; e < body; e += 16 * 64) {
+      for (int e = 16 * lt; e < body; e += 16 * lpg) {
         const uint4 q = *reinterpret_cast<const uint4*>(p + e);
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          // count non-zero bytes of a dword: fold each byte to its low bit
-          uint32_t x = w[d];
-          x |= x >> 4;
-          x |= x >> 2;
-          x |= x >> 1;
-          cnt += __popc(x & 0x01010101u);
-        }
+        cnt += count_nonzero_bytes(q.x) + count_nonzero_bytes(q.y) + count_nonzero_bytes(q.z) +
+               count_nonzero_bytes(q.w);
       }
     }
-    for (int e = body + lane; e < N; e += 64) cnt += p[e] != 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-    if (lane == 0) {
+    for (int e = body + lt; e < N; e += lpg) cnt += p[e] != 0;
+    for (int off = lpg >> 1; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lt == 0 && live) {
       done[g] = cnt == 0;
       if (nnz) nnz[g] = cnt;
     }
   }
 }
 
-// state_out[b] <- template (S^3 bytes).  One workgroup per game, grid-stride.
-__global__ __launch_bounds__(kBlock) void broadcast_kernel(const int8_t* start, int8_t* out, int64_t B, int N,
-                                                           int64_t stride, int vec16) {
-  for (int64_t g = blockIdx.x; g < B; g += gridDim.x) {
-    int8_t* dst = out + g * stride;
-    int body = 0;
-    if (vec16) {
-      body = N & ~15;
-      for (int e = 16 * threadIdx.x; e < body; e += 16 * kBlock)
-        *reinterpret_cast<uint4*>(dst + e) = *reinterpret_cast<const uint4*>(start + e);
+// state_out[b] <- template (S^3 bytes) for b in [first, B).  One thread per 16-byte chunk of the
+// whole batch (grid-stride); the template (<= 32 KiB) is served from L1/L2.  vec16 == 0: bytes.
+__global__ __launch_bounds__(kBlock) void broadcast_kernel(const int8_t* start, int8_t* out, int64_t first,
+                                                           int64_t B, int N, int64_t stride, int vec16) {
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t nthr = static_cast<int64_t>(gridDim.x) * kBlock;
+  if (vec16) {
+    const int nchunk = (N + 15) >> 4, tail = N & 15;
+    const int64_t total = (B - first) * nchunk;
+    for (int64_t idx = tid; idx < total; idx += nthr) {
+      const int64_t g = first + idx / nchunk;
+      const int c = static_cast<int>(idx - (g - first) * nchunk);
+      int8_t* dst = out + g * stride + 16 * c;
+      if (tail && c == nchunk - 1) {
+        for (int t = 0; t < tail; ++t) dst[t] = start[16 * c + t];
+      } else {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(start + 16 * c);
+      }
     }
-    for (int e = body + threadIdx.x; e < N; e += kBlock) dst[e] = start[e];
+  } else {
+    const int64_t total = (B - first) * N;
+    for (int64_t idx = tid; idx < total; idx += nthr) {
+      const int64_t g = first + idx / N;
+      const int e = static_cast<int>(idx - (g - first) * N);
+      out[g * stride + e] = start[e];
+    }
   }
 }
 
-// <n,n,n> tensor (reference utils.py:158-160): entry [p][q][r] = 1 iff p = a*n+j, q = j*n+c,
-// r = a*n+c for some a,j,c  <=>  p/n == r/n, q%n == r%n, p%n == q/n.
-__global__ __launch_bounds__(kBlock) void matmul_reset_kernel(int8_t* out, int64_t B, int n, int64_t stride) {
+// <n,n,n> tensor into ONE game slot (reference utils.py:158-160): entry [p][q][r] = 1 iff
+// p = a*n+j, q = j*n+c, r = a*n+c for some a,j,c  <=>  p/n == r/n, q%n == r%n, p%n == q/n.
+// tg_reset_matmul_i8 writes game 0 with this and broadcasts it to the other games.
+__global__ __launch_bounds__(kBlock) void matmul_template_kernel(int8_t* dst, int n) {
   const int S = n * n, N = S * S * S;
-  for (int64_t g = blockIdx.x; g < B; g += gridDim.x) {
-    int8_t* dst = out + g * stride;
-    for (int e = threadIdx.x; e < N; e += kBlock) {
-      const int p = e / (S * S), rem = e - p * S * S, q = rem / S, r = rem - q * S;
-      dst[e] = (p / n == r / n) && (q % n == r % n) && (p % n == q / n);
-    }
+  for (int e = blockIdx.x * kBlock + threadIdx.x; e < N; e += gridDim.x * kBlock) {
+    const int p = e / (S * S), rem = e - p * S * S, q = rem / S, r = rem - q * S;
+    dst[e] = (p / n == r / n) && (q % n == r % n) && (p % n == q / n);
   }
 }
 
@@ -636,6 +665,30 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
     (void)hipGetLastError(); hipLaunchKernelGGL((s4_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
     return check_launch(fn);
   }
+  // packed int16 path: exact while nact * f^3 <= 32000 for every |factor| <= f (checked on device)
+  int flim = 0;
+  {
+    const int64_t n = (MODE == MANY || MODE == GENF) ? a.nact : 1;
+    while (flim < 31 && static_cast<int64_t>(flim + 1) * (flim + 1) * (flim + 1) * n <= 32000) ++flim;
+  }
+  static const bool force_i32 = getenv("TG_FORCE_I32") != nullptr;  // A/B switch for measurements
+#define TG_PACKED(S_, TS_)                                                                      \
+  do {                                                                                          \
+    const int64_t blocks = (B + PGeo<S_, TS_>::GPB - 1) / PGeo<S_, TS_>::GPB;                   \
+    if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);              \
+    const int at = a.nact < PGeo<S_, TS_>::ATILE ? a.nact : PGeo<S_, TS_>::ATILE;               \
+    const int ldsb = packed_lds_bytes<S_, TS_, MODE>(at);                                       \
+    (void)hipGetLastError();                                                                    \
+    hipLaunchKernelGGL((packed_kernel<S_, TS_, MODE>), dim3((unsigned)blocks), dim3(kBlock),    \
+                       ldsb, st, a, flim, at);                                                  \
+    return check_launch(fn);                                                                    \
+  } while (0)
+  if (al && flim >= 1 && !force_i32) {
+    if (a.S == 9) TG_PACKED(9, 64);
+    if (a.S == 16) TG_PACKED(16, 64);
+    if (a.S == 25) TG_PACKED(25, 256);
+  }
+#undef TG_PACKED
   if (al && a.S == 9) TG_TEAM(9, 64);
   if (al && a.S == 16) TG_TEAM(16, 64);
   if (al && a.S == 25) TG_TEAM(25, 256);
@@ -707,10 +760,12 @@ int tg_done_i8(const int8_t* state, uint8_t* done, int32_t* nnz, int64_t B, int 
   if (B == 0) return TG_OK;
   if (!state || !done) return fail(TG_ERR_INVALID, "tg_done_i8: null pointer");
   const int vec16 = aligned16(state) && game_stride_bytes % 16 == 0;
-  const int64_t blocks = (B + 3) / 4;  // 4 wavefronts (games) per workgroup
-  (void)hipGetLastError(); hipLaunchKernelGGL(tg::done_kernel, dim3(capped_grid(blocks)), dim3(tg::kBlock), 0,
-                     static_cast<hipStream_t>(stream), state, done, nnz, B, S * S * S,
-                     game_stride_bytes, vec16);
+  const int N = S * S * S;
+  int lpg = 1;
+  while (lpg < 64 && lpg * 16 < N) lpg <<= 1;  // lanes per game: one 16-byte chunk each where possible
+  const int64_t blocks = (B * lpg + tg::kBlock - 1) / tg::kBlock;
+  (void)hipGetLastError(); hipLaunchKernelGGL(tg::done_kernel, dim3(capped_grid(blocks > 8192 ? 8192 : blocks)), dim3(tg::kBlock), 0,
+                     static_cast<hipStream_t>(stream), state, done, nnz, B, N, game_stride_bytes, vec16, lpg);
   return check_launch("tg_done_i8");
 }
 
@@ -720,8 +775,17 @@ int tg_reset_matmul_i8(int8_t* state_out, int64_t B, int n, int64_t game_stride_
   if (int rc = validate_common("tg_reset_matmul_i8", B, n * n, game_stride_bytes)) return rc;
   if (B == 0) return TG_OK;
   if (!state_out) return fail(TG_ERR_INVALID, "tg_reset_matmul_i8: null pointer");
-  (void)hipGetLastError(); hipLaunchKernelGGL(tg::matmul_reset_kernel, dim3(capped_grid(B)), dim3(tg::kBlock), 0,
-                     static_cast<hipStream_t>(stream), state_out, B, n, game_stride_bytes);
+  const int S = n * n, N = S * S * S;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(tg::matmul_template_kernel, dim3((N + tg::kBlock - 1) / tg::kBlock), dim3(tg::kBlock), 0, st,
+                     state_out, n);
+  if (B > 1) {
+    const int vec16 = aligned16(state_out) && game_stride_bytes % 16 == 0;
+    const int64_t work = (B - 1) * (vec16 ? (N + 15) / 16 : N);
+    hipLaunchKernelGGL(tg::broadcast_kernel, dim3(capped_grid((work + tg::kBlock - 1) / tg::kBlock > 8192 ? 8192 : (work + tg::kBlock - 1) / tg::kBlock)),
+                       dim3(tg::kBlock), 0, st, state_out, state_out, (int64_t)1, B, N, game_stride_bytes, vec16);
+  }
   return check_launch("tg_reset_matmul_i8");
 }
 
@@ -731,9 +795,11 @@ int tg_reset_broadcast_i8(const int8_t* start, int8_t* state_out, int64_t B, int
   if (B == 0) return TG_OK;
   if (!start || !state_out) return fail(TG_ERR_INVALID, "tg_reset_broadcast_i8: null pointer");
   const int vec16 = aligned16(start) && aligned16(state_out) && game_stride_bytes % 16 == 0;
-  (void)hipGetLastError(); hipLaunchKernelGGL(tg::broadcast_kernel, dim3(capped_grid(B)), dim3(tg::kBlock), 0,
-                     static_cast<hipStream_t>(stream), start, state_out, B, S * S * S,
-                     game_stride_bytes, vec16);
+  const int N = S * S * S;
+  const int64_t work = B * (vec16 ? (N + 15) / 16 : N);
+  const int64_t blocks = (work + tg::kBlock - 1) / tg::kBlock;
+  (void)hipGetLastError(); hipLaunchKernelGGL(tg::broadcast_kernel, dim3(capped_grid(blocks > 8192 ? 8192 : blocks)), dim3(tg::kBlock), 0,
+                     static_cast<hipStream_t>(stream), start, state_out, (int64_t)0, B, N, game_stride_bytes, vec16);
   return check_launch("tg_reset_broadcast_i8");
 }
 

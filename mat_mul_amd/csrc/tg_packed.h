@@ -1,0 +1,389 @@
+// Packed-int16 team kernels (included inside namespace tg by tg_kernels.hip).
+//
+// The rank-1 update of 16 consecutive state bytes needs, per element, u_i*v_j (constant along a
+// row of S elements) times w_l.  Walking an (i,j,l) cursor per element costs ~8 VALU ops and an
+// LDS lookup per element.  This form removes both:
+//
+//  * PERIOD TRICK.  Lane t of a team owns chunks c = t + TSA*n, where TSA is the largest multiple
+//    of P = S/gcd(S,16) that fits the team.  16*TSA is a multiple of S, so the position of a
+//    lane's 16-element window inside a row, l0 = 16t mod S, is the same for ALL of its chunks:
+//    the 16 weights w[(l0+k) mod S] are fetched ONCE per action (8 aligned dword reads from a
+//    periodically extended int16 copy of w in LDS) and reused for every chunk of the lane.
+//  * A window crosses at most NSEG-1 row boundaries, at lane-constant positions.  The weights are
+//    split by lane-constant masks into NSEG vectors, one per row segment; each segment's
+//    u_i*v_j is a lane-uniform scalar broadcast into both halves of a dword.
+//  * 2 MACs per instruction: acc(int16 x2) = v_pk_mad_i16(uv|uv, w pair, acc).  Bytes <-> int16
+//    pairs by v_perm_b32 (sign-extending selectors).
+//
+// 16-bit sums are exact while nact * f^3 <= 32000 (f = largest |factor|); a prescan of the
+// game's tokens decides per workgroup, and games with larger factors run the exact byte-wise
+// 32-bit form (slow_game).  The default vocabulary {-1,0,1} always takes the packed path.
+
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int S, int TS>
+struct PGeo {
+  static constexpr int N = S * S * S;
+  static constexpr int G = cgcd(S, 16);
+  static constexpr int P = S / G;                       // period of the window position, in chunks
+  static constexpr int TSA = (TS / P) * P;              // active lanes per team
+  static constexpr int NCHUNK = (N + 15) / 16;
+  static constexpr int NCH = (NCHUNK + TSA - 1) / TSA;  // chunks per lane
+  static constexpr int NSEG = 1 + (S - G + 15) / S;     // row segments a window can touch
+  static constexpr int GPB = kBlock / TS;
+  static constexpr int TAIL = N % 16;
+  static constexpr int UVLEN = 2 * S + 2;               // shorts: u[S], 0, v[S], pad
+  static constexpr int WE = (S + 16 + 1) & ~1;          // shorts per periodic copy of w (even)
+  static constexpr int FSTRIDE = UVLEN + 2 * WE;        // shorts per action (even: dword aligned)
+  static constexpr int ATILE_RAW = 32768 / (GPB * FSTRIDE * 2);
+  static constexpr int ATILE = ATILE_RAW > 64 ? 64 : ATILE_RAW;
+  static constexpr int LDS_SHORTS = GPB * ATILE * FSTRIDE;
+  static_assert(TSA >= 1 && NSEG >= 1 && NSEG <= 4 && ATILE >= 1, "geometry");
+};
+
+__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+// 16 int8 (one uint4) -> 8 dwords of two sign-extended int16 each, element order preserved
+__device__ __forceinline__ void unpack_pairs(const uint4& q, uint32_t (&A)[8]) {
+  const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t x = w[d], y = x << 8;  // y.byte1 = x.byte0, y.byte3 = x.byte2
+    A[2 * d] = __builtin_amdgcn_perm(x, y, 0x0A050804u);      // b0, sign(b0), b1, sign(b1)
+    A[2 * d + 1] = __builtin_amdgcn_perm(x, y, 0x0B070906u);  // b2, sign(b2), b3, sign(b3)
+  }
+}
+
+// low bytes of the 16 int16 -> uint4; nz |= packed bytes; ovf |= (x+128) per half (bits 8..15 set when out of range)
+__device__ __forceinline__ uint4 pack_pairs(const uint32_t (&A)[8], uint32_t& nz, uint32_t& ovf) {
+  uint32_t w[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    ovf |= pk_add_u16(A[2 * d], 0x00800080u) | pk_add_u16(A[2 * d + 1], 0x00800080u);
+    w[d] = __builtin_amdgcn_perm(A[2 * d + 1], A[2 * d], 0x06040200u);
+    nz |= w[d];
+  }
+  return uint4{w[0], w[1], w[2], w[3]};
+}
+
+// Dynamic LDS (bytes) for `at` staged actions per tile: int16 tables, raw token bytes, flags.
+template <int S, int TS, int MODE>
+constexpr int packed_lds_bytes(int at) {
+  using G = PGeo<S, TS>;
+  const int tables = G::GPB * at * G::FSTRIDE * 2;
+  const int raw = G::GPB * ((at * 3 * S + 8 + 3) & ~3);
+  const int nflag = cmax(MODE == MANY ? TG_MAX_ACTIONS : 4, 3 * G::GPB * at);
+  return tables + raw + ((nflag + 3) & ~3);
+}
+
+template <int S, int TS, int MODE>
+__global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, int at) {
+  using G = PGeo<S, TS>;
+  constexpr bool SUB = (MODE != GENF);
+  extern __shared__ __attribute__((aligned(16))) short lds[];
+  const int raw_stride = (at * 3 * S + 8 + 3) & ~3;  // bytes of raw tokens per team
+  int8_t* const raw_all = reinterpret_cast<int8_t*>(lds + G::GPB * at * G::FSTRIDE);
+  uint8_t* const flags = reinterpret_cast<uint8_t*>(raw_all + G::GPB * raw_stride);
+
+  const int tid = threadIdx.x;
+  const int team = tid / TS, lt = tid % TS;
+  int64_t g = static_cast<int64_t>(blockIdx.x) * G::GPB + team;
+  const bool live = g < a.B;
+  if (!live) g = a.B - 1;
+  const int8_t* const tok = a.actions + g * a.nact * (3 * S);
+  int8_t* const raw = raw_all + team * raw_stride;
+
+  // Raw tokens of actions [a0, a0+na) -> LDS with aligned dword loads (the dword that holds a
+  // valid byte never crosses a page, so the <= 3 stray bytes at either end are safe to read and
+  // are ignored).  All of a lane's loads are independent: one memory latency per tile.
+  // Returns whether any factor of the tile exceeds +-flim.
+  auto load_raw = [&](int a0, int na, int& head) -> int {
+    const uintptr_t A = reinterpret_cast<uintptr_t>(tok + a0 * (3 * S));
+    head = static_cast<int>(A & 3);
+    const uint32_t* A4 = reinterpret_cast<const uint32_t*>(A - head);
+    const int nbytes = na * 3 * S, ndw = (head + nbytes + 3) >> 2;
+    uint32_t* rawdw = reinterpret_cast<uint32_t*>(raw);
+    int big = 0;
+#pragma unroll 4
+    for (int idx = lt; idx < ndw; idx += TS) {
+      const uint32_t x = A4[idx];
+      rawdw[idx] = x;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int o = 4 * idx + t - head;
+        const int f = sbyte(x, t) - a.shift;
+        big |= (o >= 0 && o < nbytes) && ((f > flim) | (f < -flim));
+      }
+    }
+    return big;
+  };
+
+  // ---- do all factors of this workgroup's games fit the 16-bit path? ---------------------------
+  // Single tile (nact <= at): the range check rides on the tile's own raw load below.
+  // Several tiles: prescan every token first (the state must not be touched before the decision).
+  int head0 = 0;
+  {
+    int big = 0;
+    if (a.nact <= at) {
+      big = load_raw(0, a.nact, head0);
+    } else {
+      const uintptr_t A = reinterpret_cast<uintptr_t>(tok);
+      const int hd = static_cast<int>(A & 3);
+      const uint32_t* A4 = reinterpret_cast<const uint32_t*>(A - hd);
+      const int nbytes = a.nact * 3 * S, ndw = (hd + nbytes + 3) >> 2;
+#pragma unroll 4
+      for (int idx = lt; idx < ndw; idx += TS) {
+        const uint32_t x = A4[idx];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int o = 4 * idx + t - hd;
+          const int f = sbyte(x, t) - a.shift;
+          big |= (o >= 0 && o < nbytes) && ((f > flim) | (f < -flim));
+        }
+      }
+    }
+    if (__syncthreads_or(big)) {  // exact byte-wise form, one game at a time (rare; speed is irrelevant)
+      for (int t = 0; t < G::GPB; ++t) {
+        const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
+        if (b < a.B) slow_game<MODE>(a, b, flags);
+      }
+      return;
+    }
+  }
+
+  // ---- lane geometry ----------------------------------------------------------------------------
+  const bool active = lt < G::TSA;
+  const int l0 = (16 * lt) % S;
+  const int woff = G::UVLEN + (l0 & 1) * G::WE + (l0 & ~1);  // window start (shorts) inside an action's table
+  uint32_t mask[G::NSEG > 1 ? G::NSEG - 1 : 1][8];
+#pragma unroll
+  for (int s = 0; s + 1 < G::NSEG; ++s) {
+    const int lo = (s == 0) ? -1000 : s * S - l0, hi = (s + 1) * S - l0;  // segment s covers k in [lo,hi)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int k0 = 2 * p, k1 = 2 * p + 1;
+      mask[s][p] = ((k0 >= lo && k0 < hi) ? 0x0000FFFFu : 0u) | ((k1 >= lo && k1 < hi) ? 0xFFFF0000u : 0u);
+    }
+  }
+  bool cv[G::NCH], ctail[G::NCH];
+  int rowidx[G::NCH][G::NSEG];  // (index of u_i) | (index of v_j) << 16, both into the action's table
+#pragma unroll
+  for (int n = 0; n < G::NCH; ++n) {
+    const int c = lt + G::TSA * n;
+    cv[n] = active && c < G::NCHUNK;
+    ctail[n] = (G::TAIL != 0) && (c == G::NCHUNK - 1);
+    const int r0 = (16 * c) / S;
+#pragma unroll
+    for (int s = 0; s < G::NSEG; ++s) {
+      const int row = r0 + s;
+      int i = row / S;
+      const int j = row - i * S;
+      if (!cv[n] || i >= S) i = S;  // table[S] == 0: rows past the tensor (and idle chunks) add nothing
+      rowidx[n][s] = i | ((S + 1 + j) << 16);
+    }
+  }
+
+  // ---- state ------------------------------------------------------------------------------------
+  uint4 par[G::NCH];
+#pragma unroll
+  for (int n = 0; n < G::NCH; ++n) {
+    par[n] = uint4{0, 0, 0, 0};
+    if (MODE != GENF && cv[n])
+      par[n] = load_chunk<G::TAIL>(a.in + g * a.in_stride + 16 * (lt + G::TSA * n), ctail[n]);
+  }
+
+  short* const F = lds + team * (at * G::FSTRIDE);
+  // tile [a0,a0+na): raw tokens (already in LDS when `loaded`) -> int16 tables u,0,v,pad, w-periodic x2
+  auto stage = [&](int a0, int na, bool loaded) {
+    int head = head0;
+    if (!loaded) {
+      __syncthreads();  // previous tile's tables and raw bytes are no longer read
+      (void)load_raw(a0, na, head);
+    }
+    __syncthreads();
+    for (int r = lt; r < na * G::FSTRIDE; r += TS) {
+      const int k = r / G::FSTRIDE, pos = r - k * G::FSTRIDE;
+      const int8_t* t = raw + head + k * (3 * S);
+      int val = 0;
+      if (pos < S) {
+        val = t[pos] - a.shift;
+        if (SUB) val = -val;
+      } else if (pos > S && pos <= 2 * S) {
+        val = t[S + (pos - S - 1)] - a.shift;
+      } else if (pos >= G::UVLEN) {
+        int q = pos - G::UVLEN;
+        const int copy = q >= G::WE;
+        q -= copy * G::WE;
+        val = t[2 * S + (q + copy) % S] - a.shift;
+      }
+      F[r] = static_cast<short>(val);
+    }
+    __syncthreads();
+  };
+
+  auto apply = [&](const short* Fa, uint32_t (&A)[G::NCH][8]) {  // A += rank-1 term of one action
+    const uint32_t* wp = reinterpret_cast<const uint32_t*>(Fa + woff);
+    uint32_t ws[G::NSEG][8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint32_t w2 = wp[p];
+      if constexpr (G::NSEG == 1) {
+        ws[0][p] = w2;
+      } else if constexpr (G::NSEG == 2) {
+        ws[0][p] = w2 & mask[0][p];
+        ws[1][p] = w2 & ~mask[0][p];
+      } else {
+        uint32_t rest = w2;
+#pragma unroll
+        for (int s = 0; s + 1 < G::NSEG; ++s) {
+          ws[s][p] = w2 & mask[s][p];
+          rest ^= ws[s][p];
+        }
+        ws[G::NSEG - 1][p] = rest;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < G::NCH; ++n) {
+#pragma unroll
+      for (int s = 0; s < G::NSEG; ++s) {
+        const int uv = mul24_pinned(Fa[rowidx[n][s] & 0xffff], Fa[rowidx[n][s] >> 16]);
+        const uint32_t pr = __builtin_amdgcn_perm(static_cast<uint32_t>(uv), static_cast<uint32_t>(uv), 0x05040100u);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) A[n][p] = pk_mad_i16(pr, ws[s][p], A[n][p]);
+      }
+    }
+  };
+
+  uint32_t ovf = 0;
+
+  if constexpr (MODE == STEP) {
+    stage(0, 1, true);
+    uint32_t A[G::NCH][8];
+#pragma unroll
+    for (int n = 0; n < G::NCH; ++n) unpack_pairs(par[n], A[n]);
+    apply(F, A);
+    uint32_t nz = 0;
+#pragma unroll
+    for (int n = 0; n < G::NCH; ++n) {
+      const uint4 q = pack_pairs(A[n], nz, ovf);
+      if (live && cv[n]) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * (lt + G::TSA * n), q, ctail[n]);
+    }
+    bool any_nz, any_ovf;
+    if constexpr (TS == 256) {
+      any_nz = __syncthreads_or(nz != 0);
+      any_ovf = __syncthreads_or((ovf & 0xFF00FF00u) != 0);
+    } else {
+      any_nz = team_any<TS>(nz != 0);
+      any_ovf = team_any<TS>((ovf & 0xFF00FF00u) != 0);
+    }
+    if (lt == 0 && live) {
+      a.done[g] = any_nz ? 0 : 1;
+      if (a.overflow && any_ovf) a.overflow[g] = 1;
+    }
+  } else if constexpr (MODE == MANY || MODE == GENF) {
+    uint32_t A[G::NCH][8];
+#pragma unroll
+    for (int n = 0; n < G::NCH; ++n) unpack_pairs(par[n], A[n]);
+    int done_step = -1;
+    if constexpr (MODE == MANY && TS == 256) {
+      for (int k = tid; k < a.nact; k += kBlock) flags[k] = 0;
+    }
+    for (int a0 = 0; a0 < a.nact; a0 += at) {
+      const int na = min(at, a.nact - a0);
+      stage(a0, na, a.nact <= at);
+      for (int k = 0; k < na; ++k) {
+        apply(F + k * G::FSTRIDE, A);
+        if constexpr (MODE == MANY) {
+          uint32_t nz = 0;
+#pragma unroll
+          for (int n = 0; n < G::NCH; ++n)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+              nz |= A[n][p];
+              ovf |= pk_add_u16(A[n][p], 0x00800080u);
+            }
+          if constexpr (TS == 256) {
+            if (nz & 0x00FF00FFu) flags[a0 + k] = 1;
+          } else {
+            if (!team_any<TS>((nz & 0x00FF00FFu) != 0) && done_step < 0) done_step = a0 + k;
+          }
+        }
+      }
+    }
+    uint32_t nz = 0;
+#pragma unroll
+    for (int n = 0; n < G::NCH; ++n) {
+      const uint4 q = pack_pairs(A[n], nz, ovf);
+      if (live && cv[n]) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * (lt + G::TSA * n), q, ctail[n]);
+    }
+    bool any_ovf;
+    if constexpr (TS == 256) {
+      any_ovf = __syncthreads_or((ovf & 0xFF00FF00u) != 0);  // also orders the flag writes
+      if (MODE == MANY && tid == 0) {
+        for (int k = 0; k < a.nact; ++k)
+          if (!flags[k]) { done_step = k; break; }
+      }
+    } else {
+      any_ovf = team_any<TS>((ovf & 0xFF00FF00u) != 0);
+    }
+    if (lt == 0 && live) {
+      if constexpr (MODE == MANY) a.done_step[g] = done_step;
+      if (a.overflow && any_ovf) a.overflow[g] = 1;
+    }
+  } else {  // EXPAND
+    uint8_t* const nzF = flags + team * (3 * at);
+    uint8_t* const ovF = nzF + at;
+    uint8_t* const nnF = ovF + at;
+    for (int a0 = 0; a0 < a.nact; a0 += at) {
+      const int na = min(at, a.nact - a0);
+      stage(a0, na, a.nact <= at);
+      for (int k = lt; k < na; k += TS) {  // null action <=> u, v or w is the zero vector
+        const short* Fa = F + k * G::FSTRIDE;
+        int nu = 0, nv = 0, nw = 0;
+        for (int s = 0; s < S; ++s) {
+          nu |= Fa[s];
+          nv |= Fa[S + 1 + s];
+          nw |= Fa[G::UVLEN + s];
+        }
+        nnF[k] = (nu != 0) && (nv != 0) && (nw != 0);
+        nzF[k] = 0;
+        ovF[k] = 0;
+      }
+      __syncthreads();
+      for (int k = 0; k < na; ++k) {
+        const int64_t child = g * a.nact + a0 + k;
+        uint32_t A[G::NCH][8];
+#pragma unroll
+        for (int n = 0; n < G::NCH; ++n) unpack_pairs(par[n], A[n]);
+        apply(F + k * G::FSTRIDE, A);
+        uint32_t nz = 0, covf = 0;
+#pragma unroll
+        for (int n = 0; n < G::NCH; ++n) {
+          const uint4 q = pack_pairs(A[n], nz, covf);
+          if (live && cv[n])
+            store_chunk<G::TAIL>(a.out + child * a.out_stride + 16 * (lt + G::TSA * n), q, ctail[n]);
+        }
+        if (nz) nzF[k] = 1;
+        if (covf & 0xFF00FF00u) ovF[k] = 1;
+      }
+      __syncthreads();
+      for (int k = lt; k < na; k += TS) {
+        if (!live) continue;
+        const int64_t child = g * a.nact + a0 + k;
+        a.done[child] = nzF[k] ? 0 : 1;
+        if (a.changed) a.changed[child] = nnF[k];
+        if (a.overflow && ovF[k]) a.overflow[child] = 1;
+      }
+    }
+  }
+}
