@@ -131,6 +131,33 @@ int tg_change_basis_i8(const int8_t* state_in, const int32_t* basis, int8_t* sta
                        uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes,
                        tg_stream_t stream);
 
+/* ---- next rows ------------------------------------------------------ */
+
+/* N1, model-input assembly.  The env keeps a T-deep history ring per game: frame slot s of game b
+ * at ring + b*game_stride_bytes + s*frame_stride_bytes (int8, S^3 bytes each); the step writes the
+ * new head into slot (head_slot+1) mod T, so the reference's history shift (torch.cat of
+ * act.py:271-274) costs no copy.  This entry emits the (B,T,S,S,S) tensor the model consumes
+ * (model.py:101-122), newest frame first: out[b][f] = float(ring[b][(head_slot - f) mod T]).
+ * out: float32 (out_is_f16 == 0) or float16, C-contiguous.  scalars (may be NULL): float32 (B,1)
+ * filled with t_step (get_scalars, utils.py:22-37). */
+int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_is_f16, int64_t B, int S,
+                   int T, int head_slot, float t_step, int64_t frame_stride_bytes,
+                   int64_t game_stride_bytes, tg_stream_t stream);
+
+/* N2, transposition-table key.  hash_out[b] (uint64) = H(state[b]): with the S^3 bytes zero-padded
+ * to 8-byte little-endian words w_k, H = fmix64( (sum_k fmix64(w_k + (k+1)*0x9E3779B97F4A7C15))
+ * ^ (S^3 * 0xC2B2AE3D27D4EB4F) ), fmix64 = the MurmurHash3 finaliser.  Equal states give equal
+ * keys; replaces the 127-character string key of state_to_str (utils.py:164-169). */
+int tg_hash_u64(const int8_t* state, uint64_t* hash_out, int64_t B, int S,
+                int64_t game_stride_bytes, tg_stream_t stream);
+
+/* N3, terminal reward.  rank_out[b] (int32) = sum over the S slices state[b][i] of the rank of the
+ * S x S integer matrix, computed exactly over GF(p) for the two primes 2^31-1 and 2^31-19 (the
+ * maximum is taken; it equals the rational rank unless a minor is divisible by both primes).
+ * Replaces get_rank (utils.py:134-140: float SVD rank, summed). */
+int tg_rank_i32(const int8_t* state, int32_t* rank_out, int64_t B, int S,
+                int64_t game_stride_bytes, tg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

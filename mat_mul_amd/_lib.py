@@ -37,6 +37,9 @@ SIGNATURES = {
     "tg_gen_demos_i8": [_p, _p, _p, _i64, _i, _i, _p, _p, _i, _i, _u64, _u64, _p, _i64, _p],
     "tg_sample_basis_i8": [_p, _p, _p, _i64, _i, _p, _p, _i, _u64, _u64, _p],
     "tg_change_basis_i8": [_p, _p, _p, _p, _i64, _i, _i64, _p],
+    "tg_emit_frames": [_p, _p, _p, _i, _i64, _i, _i, _i, C.c_float, _i64, _i64, _p],
+    "tg_hash_u64": [_p, _p, _i64, _i, _i64, _p],
+    "tg_rank_i32": [_p, _p, _i64, _i, _i64, _p],
 }
 
 

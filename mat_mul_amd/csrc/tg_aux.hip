@@ -1,0 +1,271 @@
+// "Next rows" of the hot path: model-input assembly (N1), state hashing
+// (N2) and the exact slice-rank reward (N3).  gfx950 only; part of libtensorgame.so.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "../../include/tensor_game.h"
+#include "tg_device.h"
+
+int tg_internal_fail(int code, const char* fmt, ...);  // tg_kernels.hip
+
+namespace tg {
+
+// ---------------------------------------------------------------------------------------------
+// N1: int8 history ring -> float model input.  One thread per 16 input bytes (64 or 32 output
+// bytes); HBM-bound on the float write: S^3*T*(1 + 4) bytes per game for float32.
+// ---------------------------------------------------------------------------------------------
+template <typename OutT>
+__global__ __launch_bounds__(kBlock) void emit_frames_kernel(const int8_t* ring, OutT* out, float* scalars,
+                                                             int64_t B, int N, int T, int head_slot, float t_step,
+                                                             int64_t frame_stride, int64_t game_stride, int vec16) {
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t nthr = static_cast<int64_t>(gridDim.x) * kBlock;
+  if (scalars)
+    for (int64_t b = tid; b < B; b += nthr) scalars[b] = t_step;
+  const int nchunk = (N + 15) >> 4;
+  const int64_t total = B * T * nchunk;
+  for (int64_t idx = tid; idx < total; idx += nthr) {
+    const int64_t bf = idx / nchunk;  // b*T + f
+    const int c = static_cast<int>(idx - bf * nchunk);
+    const int64_t b = bf / T;
+    const int f = static_cast<int>(bf - b * T);
+    int slot = head_slot - f;
+    if (slot < 0) slot += T;
+    const int8_t* src = ring + b * game_stride + slot * frame_stride + 16 * c;
+    OutT* dst = out + bf * N + 16 * c;
+    const int nvalid = min(16, N - 16 * c);
+    if (vec16 && nvalid == 16) {
+      const uint4 q = *reinterpret_cast<const uint4*>(src);
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+      OutT v[16];
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[4 * d + t] = static_cast<OutT>(static_cast<float>(sbyte(w[d], t)));
+      // N*sizeof(OutT) need not be a multiple of 16: vector stores only when the destination is aligned
+      if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        constexpr int PER = 16 / sizeof(OutT);
+#pragma unroll
+        for (int k = 0; k < 16 / PER; ++k) {
+          uint4 o;
+          __builtin_memcpy(&o, &v[k * PER], 16);
+          reinterpret_cast<uint4*>(dst)[k] = o;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dst[t] = v[t];
+      }
+    } else {
+      for (int t = 0; t < nvalid; ++t) dst[t] = static_cast<OutT>(static_cast<float>(src[t]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// N2: 64-bit state hash.  Team of lpg lanes per game (as done_kernel), 16 bytes = two words per
+// lane-iteration, wrapping sum across the team (order independent => any lane mapping is valid).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xFF51AFD7ED558CCDull;
+  k ^= k >> 33;
+  k *= 0xC4CEB9FE1A85EC53ull;
+  k ^= k >> 33;
+  return k;
+}
+
+__global__ __launch_bounds__(kBlock) void hash_kernel(const int8_t* state, uint64_t* out, int64_t B, int N,
+                                                      int64_t stride, int vec16, int lpg) {
+  const int lt = threadIdx.x & (lpg - 1);
+  const int64_t team = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / lpg;
+  const int64_t nteam = (static_cast<int64_t>(gridDim.x) * kBlock) / lpg;
+  const int64_t rounds = (B + nteam - 1) / nteam;
+  const int nword = (N + 7) >> 3;
+  for (int64_t it = 0; it < rounds; ++it) {
+    const int64_t g = team + it * nteam;
+    const bool live = g < B;
+    const int8_t* p = state + (live ? g : B - 1) * stride;
+    uint64_t h = 0;
+    int body_words = 0;
+    if (vec16) {
+      body_words = (N >> 4) << 1;  // whole 16-byte chunks
+      for (int c = lt; 16 * c + 16 <= N; c += lpg) {
+        const uint4 q = *reinterpret_cast<const uint4*>(p + 16 * c);
+        const uint64_t w0 = static_cast<uint64_t>(q.x) | (static_cast<uint64_t>(q.y) << 32);
+        const uint64_t w1 = static_cast<uint64_t>(q.z) | (static_cast<uint64_t>(q.w) << 32);
+        h += fmix64(w0 + static_cast<uint64_t>(2 * c + 1) * 0x9E3779B97F4A7C15ull);
+        h += fmix64(w1 + static_cast<uint64_t>(2 * c + 2) * 0x9E3779B97F4A7C15ull);
+      }
+    }
+    for (int k = body_words + lt; k < nword; k += lpg) {  // remaining words, byte by byte, zero padded
+      uint64_t w = 0;
+      for (int t = 0; t < 8; ++t) {
+        const int e = 8 * k + t;
+        if (e < N) w |= static_cast<uint64_t>(static_cast<uint8_t>(p[e])) << (8 * t);
+      }
+      h += fmix64(w + static_cast<uint64_t>(k + 1) * 0x9E3779B97F4A7C15ull);
+    }
+    for (int off = lpg >> 1; off > 0; off >>= 1) h += __shfl_xor(h, off);
+    if (lt == 0 && live) out[g] = fmix64(h ^ (static_cast<uint64_t>(N) * 0xC2B2AE3D27D4EB4Full));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// N3: sum of slice ranks.  One wavefront per (game, slice i): lane r holds row r of the S x S
+// matrix state[b][i] reduced mod p; S elimination steps, each a ballot (pivot search), a broadcast
+// of the pivot row (readlane via shuffle) and a cross-multiplied update (no modular inverse):
+// row_r <- row_r * piv_c - row_p * row_r[c]  (mod p).  Run for two primes, ranks maxed.
+// ---------------------------------------------------------------------------------------------
+template <uint32_t P>
+__device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) {
+  return static_cast<uint32_t>((static_cast<uint64_t>(a) * b) % P);
+}
+
+template <int ST, uint32_t P>
+__device__ __forceinline__ int slice_rank(const int8_t* m, int S, int lane) {
+  constexpr int SMAX = ST ? ST : TG_MAX_S;
+  uint32_t row[SMAX];
+#pragma unroll
+  for (int c = 0; c < SMAX; ++c) {
+    int v = (lane < S && c < S) ? m[lane * S + c] : 0;
+    row[c] = v < 0 ? P - static_cast<uint32_t>(-v) : static_cast<uint32_t>(v);
+  }
+  bool used = lane >= S;  // rows already chosen as pivots (and the idle lanes)
+  int rank = 0;
+#pragma unroll
+  for (int c = 0; c < SMAX; ++c) {
+    if (c < S) {
+      const uint64_t cand = __ballot(!used && row[c] != 0);
+      if (cand) {
+        const int pr = __ffsll(static_cast<long long>(cand)) - 1;  // pivot row (wave-uniform)
+        const uint32_t pc = __shfl(row[c], pr);
+        const uint32_t mine = row[c];
+        const bool upd = !used && lane != pr && mine != 0;
+#pragma unroll
+        for (int k = 0; k < SMAX; ++k) {
+          if (k < S) {
+            const uint32_t pk = __shfl(row[k], pr);
+            if (upd) {
+              const uint32_t a = mulmod<P>(row[k], pc), b = mulmod<P>(pk, mine);
+              row[k] = a >= b ? a - b : a + P - b;
+            }
+          }
+        }
+        if (lane == pr) used = true;
+        ++rank;
+      }
+    }
+  }
+  return rank;
+}
+
+template <int ST>
+__global__ __launch_bounds__(kBlock) void rank_kernel(const int8_t* state, int32_t* out, int64_t B, int Srt,
+                                                      int64_t stride) {
+  __shared__ int partial[kBlock / 64];
+  const int S = ST ? ST : Srt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // one workgroup per game: its 4 wavefronts walk the S slices
+  for (int64_t g = blockIdx.x; g < B; g += gridDim.x) {
+    int acc = 0;
+    for (int i = wave; i < S; i += kBlock / 64) {
+      const int8_t* m = state + g * stride + i * S * S;
+      const int r1 = slice_rank<ST, 2147483647u>(m, S, lane);
+      const int r2 = slice_rank<ST, 2147483629u>(m, S, lane);
+      acc += r1 > r2 ? r1 : r2;
+    }
+    if (lane == 0) partial[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < kBlock / 64; ++w) t += partial[w];
+      out[g] = t;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace tg
+
+namespace {
+int launched(const char* fn) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tg_internal_fail(TG_ERR_HIP, "%s: %s", fn, hipGetErrorString(e));
+  return TG_OK;
+}
+unsigned grid_for(int64_t blocks, int64_t cap) {
+  return static_cast<unsigned>(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+int check_state(const char* fn, int64_t B, int S, int64_t stride) {
+  if (B < 0 || S < 1 || S > TG_MAX_S || stride < (int64_t)S * S * S)
+    return tg_internal_fail(TG_ERR_INVALID, "%s: bad B/S/stride", fn);
+  return TG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_is_f16, int64_t B, int S,
+                   int T, int head_slot, float t_step, int64_t frame_stride_bytes,
+                   int64_t game_stride_bytes, tg_stream_t stream) {
+  const char* fn = "tg_emit_frames";
+  if (int rc = check_state(fn, B, S, frame_stride_bytes)) return rc;
+  if (T < 1 || T > 64 || head_slot < 0 || head_slot >= T)
+    return tg_internal_fail(TG_ERR_INVALID, "%s: need 1 <= T <= 64 and 0 <= head_slot < T", fn);
+  if (game_stride_bytes < (int64_t)(T - 1) * frame_stride_bytes + (int64_t)S * S * S)
+    return tg_internal_fail(TG_ERR_INVALID, "%s: game_stride_bytes too small for T frames", fn);
+  if (B == 0) return TG_OK;
+  if (!ring || !out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  const int N = S * S * S;
+  const int vec16 = (reinterpret_cast<uintptr_t>(ring) & 15) == 0 && frame_stride_bytes % 16 == 0 &&
+                    game_stride_bytes % 16 == 0;
+  const int64_t work = B * T * ((N + 15) / 16);
+  const dim3 grid(grid_for((work + tg::kBlock - 1) / tg::kBlock, 16384)), block(tg::kBlock);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  (void)hipGetLastError();
+  if (out_is_f16)
+    hipLaunchKernelGGL(tg::emit_frames_kernel<__half>, grid, block, 0, st, ring, static_cast<__half*>(out), scalars,
+                       B, N, T, head_slot, t_step, frame_stride_bytes, game_stride_bytes, vec16);
+  else
+    hipLaunchKernelGGL(tg::emit_frames_kernel<float>, grid, block, 0, st, ring, static_cast<float*>(out), scalars,
+                       B, N, T, head_slot, t_step, frame_stride_bytes, game_stride_bytes, vec16);
+  return launched(fn);
+}
+
+int tg_hash_u64(const int8_t* state, uint64_t* hash_out, int64_t B, int S, int64_t game_stride_bytes,
+                tg_stream_t stream) {
+  const char* fn = "tg_hash_u64";
+  if (int rc = check_state(fn, B, S, game_stride_bytes)) return rc;
+  if (B == 0) return TG_OK;
+  if (!state || !hash_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  const int N = S * S * S;
+  const int vec16 = (reinterpret_cast<uintptr_t>(state) & 15) == 0 && game_stride_bytes % 16 == 0;
+  int lpg = 1;
+  while (lpg < 64 && lpg * 16 < N) lpg <<= 1;
+  const int64_t blocks = (B * lpg + tg::kBlock - 1) / tg::kBlock;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(tg::hash_kernel, dim3(grid_for(blocks, 8192)), dim3(tg::kBlock), 0,
+                     static_cast<hipStream_t>(stream), state, hash_out, B, N, game_stride_bytes, vec16, lpg);
+  return launched(fn);
+}
+
+int tg_rank_i32(const int8_t* state, int32_t* rank_out, int64_t B, int S, int64_t game_stride_bytes,
+                tg_stream_t stream) {
+  const char* fn = "tg_rank_i32";
+  if (int rc = check_state(fn, B, S, game_stride_bytes)) return rc;
+  if (B == 0) return TG_OK;
+  if (!state || !rank_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  const dim3 grid(grid_for(B, 1 << 20)), block(tg::kBlock);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  (void)hipGetLastError();
+  switch (S) {
+    case 4: hipLaunchKernelGGL(tg::rank_kernel<4>, grid, block, 0, st, state, rank_out, B, S, game_stride_bytes); break;
+    case 9: hipLaunchKernelGGL(tg::rank_kernel<9>, grid, block, 0, st, state, rank_out, B, S, game_stride_bytes); break;
+    case 16: hipLaunchKernelGGL(tg::rank_kernel<16>, grid, block, 0, st, state, rank_out, B, S, game_stride_bytes); break;
+    case 25: hipLaunchKernelGGL(tg::rank_kernel<25>, grid, block, 0, st, state, rank_out, B, S, game_stride_bytes); break;
+    default: hipLaunchKernelGGL(tg::rank_kernel<0>, grid, block, 0, st, state, rank_out, B, S, game_stride_bytes); break;
+  }
+  return launched(fn);
+}
+
+}  // extern "C"

@@ -26,16 +26,25 @@ class TensorGameEnv:
     """
 
     def __init__(self, batch_size: int, dim_3d: int, device="cuda", shift: int = 1,
-                 track_overflow: bool = True, game_id_offset: int = 0):
+                 track_overflow: bool = True, game_id_offset: int = 0, dim_t: int = 1):
         self.B, self.S, self.shift = int(batch_size), int(dim_3d), int(shift)
+        self.T = int(dim_t)  # history depth (reference --dim_t, training.py:75); 1 = head only
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise TensorGameError("TensorGameEnv", -1, "a ROCm device is required; there is no CPU path")
         self.game_id_offset = int(game_id_offset)
-        self.state = ops.alloc_states(self.B, self.S, self.device)
+        # T frame slots per game; the head lives in slot self.head and every step writes the next
+        # slot, so the reference's history shift (act.py:271-274) is a pointer bump, not a copy
+        self.ring = ops.alloc_ring(self.B, self.S, self.T, self.device)
+        self.head = 0
         self.done = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
         self.overflow = torch.zeros((self.B,), dtype=torch.uint8, device=self.device) if track_overflow else None
         self.t = 0
+
+    @property
+    def state(self) -> torch.Tensor:
+        """The current head state, int8 (B,S,S,S) (a view of the ring's head slot)."""
+        return self.ring[:, self.head]
 
     @classmethod
     def sharded(cls, global_batch: int, dim_3d: int, rank: int, world_size: int, device, **kw):
@@ -47,7 +56,16 @@ class TensorGameEnv:
     def reset(self, start: Optional[torch.Tensor] = None) -> torch.Tensor:
         """start=None: every game <- the <n,n,n> matmul tensor, n = sqrt(dim_3d)
         (datasets.py:273-277).  start (S,S,S): broadcast.  start (B,S,S,S): copied."""
-        if start is None:
+        if self.T > 1:
+            self.ring.zero_()  # history frames of a fresh game are zero (build_matmul_tensor, utils.py:157)
+        self.head = 0
+        if start is not None and torch.as_tensor(start).dim() == 5:  # a full (B,T,S,S,S) history, newest first
+            start = torch.as_tensor(start).to(device=self.device, dtype=torch.int8)
+            if tuple(start.shape) != tuple(self.ring.shape):
+                raise TensorGameError("reset", -1, f"history must be {tuple(self.ring.shape)}")
+            for f in range(self.T):  # frame f (f steps old) -> slot (head - f) mod T
+                self.ring[:, (self.head - f) % self.T].copy_(start[:, f])
+        elif start is None:
             n = math.isqrt(self.S)
             if n * n != self.S:
                 raise TensorGameError("reset", -1, f"dim_3d={self.S} is not a perfect square; pass a start tensor")
@@ -72,7 +90,10 @@ class TensorGameEnv:
         converted with a range check).  Returns (state, done)."""
         if actions.dtype != torch.int8:
             actions = ops.as_tokens(actions, self.device)
-        ops.step(self.state, actions, out=self.state, done=self.done, overflow=self.overflow, shift=self.shift)
+        nxt = (self.head + 1) % self.T
+        ops.step(self.ring[:, self.head], actions, out=self.ring[:, nxt], done=self.done, overflow=self.overflow,
+                 shift=self.shift)
+        self.head = nxt
         self.t += 1
         return self.state, self.done
 
@@ -80,6 +101,8 @@ class TensorGameEnv:
         """K actions per game in one launch (state stays on chip).  Returns (state, done_step)."""
         if actions.dtype != torch.int8:
             actions = ops.as_tokens(actions, self.device)
+        if self.T > 1:
+            raise TensorGameError("step_many", -1, "step_many keeps no history; use step() when dim_t > 1")
         _, done_step = ops.step_many(self.state, actions, out=self.state, overflow=self.overflow, shift=self.shift)
         self.t += actions.shape[1]
         return self.state, done_step
@@ -89,6 +112,18 @@ class TensorGameEnv:
         if actions.dtype != torch.int8:
             actions = ops.as_tokens(actions, self.device)
         return ops.expand(self.state, actions, shift=self.shift)
+
+    def model_input(self, dtype=torch.float32):
+        """(state (B,T,S,S,S) float, scalars (B,1)) as AlphaTensor.fwd_* consume them
+        (model.py:101-122): newest frame first, scalars = the time step (utils.py:22-37)."""
+        return ops.emit_frames(self.ring, self.head, float(self.t), dtype=dtype)
+
+    def hash(self) -> torch.Tensor:
+        return ops.state_hash(self.state)
+
+    def rank_reward(self) -> torch.Tensor:
+        """-sum of slice ranks per game: the terminal reward of act.py:59 / :214."""
+        return -ops.slice_rank(self.state)
 
     def nnz(self) -> torch.Tensor:
         return ops.done(self.state, want_nnz=True)[1]

@@ -19,7 +19,7 @@ from ._lib import TG_MAX_ACTIONS, TG_MAX_S, TG_MAX_VALUES, TensorGameError, call
 __all__ = [
     "step", "prepare_step", "step_many", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
     "gen_demos", "sample_basis", "change_basis", "as_tokens", "categorical_thresholds",
-    "alloc_states",
+    "alloc_states", "alloc_ring", "emit_frames", "state_hash", "slice_rank",
 ]
 
 
@@ -330,4 +330,60 @@ def change_basis(state, basis, out=None, overflow=None):
     overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
     with torch.cuda.device(dev):
         call("tg_change_basis_i8", _ptr(state), _ptr(basis), _ptr(out), _ptr(overflow), B, S, stride, _stream(dev))
+    return out
+
+
+def alloc_ring(B: int, S: int, T: int, device, pad_to: int = 16) -> torch.Tensor:
+    """Zeroed history ring int8 (B,T,S,S,S): T frame slots per game, each padded to ``pad_to`` bytes.
+    ``ring[:, s]`` is a valid (B,S,S,S) state for every entry point (game stride = T * frame stride)."""
+    n = S ** 3
+    fs = -(-n // pad_to) * pad_to
+    buf = torch.zeros((B, T, fs), dtype=torch.int8, device=device)
+    return buf[:, :, :n].unflatten(2, (S, S, S))
+
+
+def emit_frames(ring, head_slot: int, t_step: float = 0.0, dtype=torch.float32, out=None, scalars=None):
+    """(B,T,S,S,S) model input from the history ring, newest frame first, plus the (B,1) scalars.
+    == the history shift of get_child_states (act.py:271-274) + get_scalars (utils.py:22-37)."""
+    _need_gpu(ring, "ring")
+    if ring.dtype != torch.int8 or ring.dim() != 5 or not (ring.shape[2] == ring.shape[3] == ring.shape[4]):
+        raise TensorGameError("emit_frames", -1, f"ring must be int8 (B,T,S,S,S), got {ring.dtype} {tuple(ring.shape)}")
+    B, T, S = ring.shape[0], ring.shape[1], ring.shape[2]
+    if ring.stride()[2:] != (S * S, S, 1):
+        raise TensorGameError("emit_frames", -1, "each frame must be C-contiguous (S,S,S)")
+    fs = ring.stride(1) if T > 1 else S ** 3
+    gs = ring.stride(0) if B > 1 else max(ring.stride(0), (T - 1) * fs + S ** 3)
+    if dtype not in (torch.float32, torch.float16):
+        raise TensorGameError("emit_frames", -1, "dtype must be float32 or float16")
+    dev = ring.device
+    if out is None:
+        out = torch.empty((B, T, S, S, S), dtype=dtype, device=dev)
+    if out.dtype != dtype or tuple(out.shape) != (B, T, S, S, S) or not out.is_contiguous() or out.device != dev:
+        raise TensorGameError("emit_frames", -1, "out must be contiguous (B,T,S,S,S) of the requested dtype")
+    if scalars is None:
+        scalars = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    scalars = _flag(scalars, (B, 1), torch.float32, dev, "scalars")
+    with torch.cuda.device(dev):
+        call("tg_emit_frames", _ptr(ring), _ptr(out), _ptr(scalars), int(dtype == torch.float16), B, S, T,
+             int(head_slot) % T, C.c_float(float(t_step)), fs, gs, _stream(dev))
+    return out, scalars
+
+
+def state_hash(state) -> torch.Tensor:
+    """64-bit key per game (int64 tensor holding the uint64 bits): the transposition-table key that
+    replaces state_to_str (utils.py:164-169).  Equal states <=> equal keys (up to 2^-64 collisions)."""
+    B, S, stride = _state_layout(state, "state")
+    out = torch.empty((B,), dtype=torch.int64, device=state.device)
+    with torch.cuda.device(state.device):
+        call("tg_hash_u64", _ptr(state), _ptr(out), B, S, stride, _stream(state.device))
+    return out
+
+
+def slice_rank(state) -> torch.Tensor:
+    """int32 (B,): sum over the S slices state[b][i] of the exact rank of the S x S matrix
+    (== get_rank per game, utils.py:134-140, which sums torch.linalg.matrix_rank over slices)."""
+    B, S, stride = _state_layout(state, "state")
+    out = torch.empty((B,), dtype=torch.int32, device=state.device)
+    with torch.cuda.device(state.device):
+        call("tg_rank_i32", _ptr(state), _ptr(out), B, S, stride, _stream(state.device))
     return out

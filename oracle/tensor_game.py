@@ -386,3 +386,74 @@ def unimodular_inverse(L, U):
     Linv = inv_lower(L)
     Uinv = np.swapaxes(inv_lower(np.swapaxes(U, -1, -2)), -1, -2)
     return Uinv @ Linv
+
+
+# ---- next rows ----------------------------------------------------------
+
+
+def model_input(frames_newest_first, t_step, dtype=np.float32):
+    """N1: what the reference feeds the model after a step -- the (B,T,S,S,S) float state whose
+    frame 0 is the new head and frames 1.. the previous frames (act.py:271-274), and
+    get_scalars (utils.py:22-37): a (B,1) float tensor filled with t_step."""
+    f = np.asarray(frames_newest_first)
+    return f.astype(dtype), np.full((f.shape[0], 1), float(t_step), np.float32)
+
+
+def _fmix64(k):
+    k = np.asarray(k, np.uint64)
+    k = k ^ (k >> np.uint64(33))
+    k = k * np.uint64(0xFF51AFD7ED558CCD)
+    k = k ^ (k >> np.uint64(33))
+    k = k * np.uint64(0xC4CEB9FE1A85EC53)
+    k = k ^ (k >> np.uint64(33))
+    return k
+
+
+def state_hash(state) -> np.ndarray:
+    """N2: the 64-bit key of include/tensor_game.h::tg_hash_u64 (replaces state_to_str,
+    utils.py:164-169).  Returns uint64 (B,)."""
+    st = np.ascontiguousarray(np.asarray(state).astype(np.int8))
+    B = st.shape[0]
+    N = st[0].size
+    nword = (N + 7) // 8
+    buf = np.zeros((B, nword * 8), np.uint8)
+    buf[:, :N] = st.reshape(B, N).view(np.uint8)
+    words = buf.view("<u8").reshape(B, nword)
+    with np.errstate(over="ignore"):
+        salt = (np.arange(1, nword + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))[None, :]
+        h = _fmix64(words + salt).sum(axis=1, dtype=np.uint64)
+        return _fmix64(h ^ (np.uint64(N) * np.uint64(0xC2B2AE3D27D4EB4F)))
+
+
+def _rank_bareiss(m):
+    """Exact rational rank of an integer matrix (list of lists of Python ints): Bareiss
+    fraction-free elimination -- every division is exact, entries stay minors of the input."""
+    n_rows, n_cols = len(m), len(m[0])
+    m = [row[:] for row in m]
+    rank, prev = 0, 1
+    for c in range(n_cols):
+        piv = next((r for r in range(rank, n_rows) if m[r][c] != 0), None)
+        if piv is None:
+            continue
+        m[rank], m[piv] = m[piv], m[rank]
+        p = m[rank][c]
+        for r in range(rank + 1, n_rows):
+            f = m[r][c]
+            m[r] = [(p * x - f * y) // prev for x, y in zip(m[r], m[rank])]
+        prev = p
+        rank += 1
+        if rank == n_rows:
+            break
+    return rank
+
+
+def slice_rank_exact(state) -> np.ndarray:
+    """N3: sum over slices state[b][i] of the EXACT rational rank of the S x S integer matrix.
+    The reference's get_rank (utils.py:134-140) is the float-SVD version of the same quantity;
+    they agree on the golden states (tests/golden/next_rows.npz)."""
+    st = np.asarray(state).astype(np.int64)
+    B, S = st.shape[0], st.shape[1]
+    out = np.zeros(B, np.int32)
+    for b in range(B):
+        out[b] = sum(_rank_bareiss([[int(x) for x in row] for row in st[b, i]]) for i in range(S))
+    return out

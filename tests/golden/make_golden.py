@@ -169,6 +169,32 @@ def main():
         stats[key + "_terms_attempts"] = np.array([n_terms, attempts], np.int64)
     np.savez_compressed(OUT / "sampler_stats.npz", **stats)
 
+    # ---------------------------------------------------------------- 7. get_rank (terminal reward), multi-step histories
+    nxt = {}
+    for (S, B) in [(4, 40), (9, 12), (16, 4), (25, 2)]:
+        st = torch.from_numpy(rng.integers(-1, 2, size=(B, 1, S, S, S)).astype(np.float32))
+        st[::3] *= (torch.from_numpy(rng.random((len(st[::3]), 1, S, S, S))) < 0.15).float()   # sparse states
+        for b in range(1, B, 4):                                                        # low-rank states
+            acs = torch.from_numpy(rng.integers(0, 3, size=(3, 3 * S)).astype(np.int64))
+            st[b, 0] = utils.action_to_tensor(acs).sum(0).float()
+        nxt[f"rank_S{S}_state"] = i8(st[:, 0])
+        nxt[f"rank_S{S}_rank"] = np.array([utils.get_rank(st[b:b + 1]) for b in range(B)], np.int32)
+    # a 5-step rollout with T=3 history through get_child_states (k=1), recording every state
+    for (S, B, T) in [(4, 6, 3), (9, 3, 2)]:
+        st = torch.zeros((B, T, S, S, S))
+        st[:, 0] = torch.from_numpy(rng.integers(-1, 2, size=(B, S, S, S)).astype(np.float32))
+        seq, acts = [i8(st)], []
+        for step in range(5):
+            ac = torch.from_numpy(rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 1, 3 * S)).astype(np.int64))
+            st = act.get_child_states(st, ac)[0]
+            seq.append(i8(st))
+            acts.append(i8(ac[:, 0]))
+            sc = utils.get_scalars(st, step + 1)
+            assert sc.shape == (B, 1) and float(sc[0, 0]) == step + 1
+        nxt[f"hist_S{S}_T{T}_states"] = np.stack(seq)       # (6,B,T,S,S,S)
+        nxt[f"hist_S{S}_T{T}_actions"] = np.stack(acts)     # (5,B,3S)
+    np.savez_compressed(OUT / "next_rows.npz", **nxt)
+
     total = sum(f.stat().st_size for f in OUT.glob("*.npz"))
     print(f"wrote {len(list(OUT.glob('*.npz')))} fixtures, {total / 1024:.0f} KiB total")
 

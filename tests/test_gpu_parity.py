@@ -392,3 +392,64 @@ def test_graph_capture_of_steps():
     graph.replay()
     torch.cuda.synchronize()
     assert bool(env.done.all()) and not bool(env.state.any())
+
+
+# ------------------------------------------------------------------ next rows: N1 history / model input, N2 hash, N3 rank
+def test_history_ring_and_model_input_golden(golden):
+    g = golden("next_rows")
+    for tag, S, T in (("hist_S4_T3", 4, 3), ("hist_S9_T2", 9, 2)):
+        states, acts = g[tag + "_states"], g[tag + "_actions"]
+        B = states.shape[1]
+        env = TensorGameEnv(B, S, DEV, dim_t=T)
+        env.reset(dev(states[0]))
+        x, sc = env.model_input()
+        assert np.array_equal(host(x), states[0].astype(np.float32))
+        for k in range(len(acts)):
+            env.step(dev(acts[k]))
+            for dt in (torch.float32, torch.float16):
+                x, sc = env.model_input(dt)
+                assert x.dtype == dt and np.array_equal(host(x).astype(np.float32), states[k + 1].astype(np.float32)), (tag, k)
+            assert host(sc).tolist() == [[float(k + 1)]] * B
+    # fresh games: zero history (build_matmul_tensor(dim_t, ...), utils.py:157), odd sizes / unaligned frames
+    env = TensorGameEnv(5, 9, DEV, dim_t=4)
+    env.reset()
+    x, _ = env.model_input()
+    want = np.broadcast_to(O.build_matmul_tensor(4, 3, 3, 3), (5, 4, 9, 9, 9)).astype(np.float32)
+    assert np.array_equal(host(x), want)
+    ring = torch.randint(-5, 6, (3, 2, 5, 5, 5), dtype=torch.int8, device=DEV)  # packed 125-byte frames
+    x, _ = ops.emit_frames(ring, 1, 0.0)
+    assert np.array_equal(host(x), host(ring)[:, ::-1].astype(np.float32))
+
+
+def test_state_hash_matches_oracle(golden):
+    rng = np.random.default_rng(3)
+    for S, B in [(4, 448), (9, 33), (16, 9), (25, 5), (5, 17), (1, 3)]:
+        st = rng.integers(-3, 4, size=(B, S, S, S)).astype(np.int8)
+        if S == 4:
+            st = golden("strassen")["ds_states"]
+        want = O.state_hash(st)
+        for t in (padded(st), dev(st)):
+            got = host(ops.state_hash(t)).view(np.uint64)
+            assert np.array_equal(got, want), S
+    s = golden("strassen")["ds_states"]
+    keys = host(ops.state_hash(padded(s)))
+    strings = ["_".join(map(str, x.reshape(-1))) for x in s]
+    assert len(set(keys.tolist())) == len(set(strings))
+
+
+def test_slice_rank_golden_and_oracle(golden):
+    g = golden("next_rows")
+    for S in (4, 9, 16, 25):
+        st = g[f"rank_S{S}_state"]
+        got = host(ops.slice_rank(padded(st)))
+        assert np.array_equal(got, g[f"rank_S{S}_rank"]), S          # == reference get_rank per game
+        assert np.array_equal(got, O.slice_rank_exact(st))
+    rng = np.random.default_rng(9)
+    for S in (3, 6, 32):
+        st = rng.integers(-2, 3, size=(4, S, S, S)).astype(np.int8)
+        st[0] = 0
+        st[1, :, 1:] = st[1, :, :1]                                  # every slice has rank <= 1
+        assert np.array_equal(host(ops.slice_rank(dev(st))), O.slice_rank_exact(st))
+    env = TensorGameEnv(3, 4, DEV)
+    env.reset()
+    assert host(env.rank_reward()).tolist() == [-8, -8, -8]           # <2,2,2>: four slices of rank 2

@@ -166,3 +166,23 @@ def test_ref_dtype_port(golden):
         assert np.array_equal(got, g[tag + "_children"].astype(np.float32)), tag
         new, done = P.env_step(st, ac[:, :1])
         assert np.array_equal(done.numpy().astype(np.uint8), g[tag + "_done"][:, 0]), tag
+
+
+def test_next_rows_oracle(golden):
+    """N1-N3: history rollouts, exact slice rank vs the reference's get_rank, hash sanity."""
+    g = golden("next_rows")
+    for S in (4, 9, 16, 25):
+        assert np.array_equal(O.slice_rank_exact(g[f"rank_S{S}_state"]), g[f"rank_S{S}_rank"]), S
+    for tag in ("hist_S4_T3", "hist_S9_T2"):
+        states, acts = g[tag + "_states"], g[tag + "_actions"]
+        cur = states[0]
+        for k in range(len(acts)):
+            cur = O.get_child_states(cur, acts[k][:, None, :])[0]
+            assert np.array_equal(cur, states[k + 1]), (tag, k)
+            x, sc = O.model_input(cur, k + 1)
+            assert x.dtype == np.float32 and sc.shape == (cur.shape[0], 1) and sc[0, 0] == k + 1
+    s = golden("strassen")["ds_states"]
+    h = O.state_hash(s)
+    strings = ["_".join(map(str, x.reshape(-1))) for x in s]      # the reference's key (utils.py:164-169)
+    assert len(set(h.tolist())) == len(set(strings))              # equal keys <=> equal states on all 448
+    assert len({(a, b) for a, b in zip(h.tolist(), strings)}) == len(set(strings))
