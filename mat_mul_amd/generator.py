@@ -37,6 +37,20 @@ class SyntheticDemos:
     def __len__(self) -> int:
         return self.n_demos * self.max_actions
 
+    def save(self, path) -> None:
+        """One packed int8 file for the whole dataset (demo_io.save_packed)."""
+        from . import demo_io
+
+        demo_io.save_packed(path, self.action_seq, self.target_tensor.contiguous(), self.shift, self.seed,
+                            self.game_id_offset)
+
+    def export_reference_layout(self, save_dir) -> int:
+        """Write ``action_seq_{i}.pt`` / ``target_tensor_{i}.pt`` exactly as the reference does
+        (datasets.py:62-69), so its SyntheticDemoDataset(overwrite=False, save_dir=...) reads them."""
+        from . import demo_io
+
+        return demo_io.export_reference_layout(save_dir, self.action_seq, self.target_tensor, self.game_id_offset)
+
     def take_actions(self, idx_action: int) -> torch.Tensor:
         """State of every demo after un-doing the actions that FOLLOW ``idx_action``
         (datasets.py:90-92): target - sum_{j > idx} tensor(a_j)."""
