@@ -203,6 +203,27 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
   }
 
   short* const F = lds + team * (at * G::FSTRIDE);
+  // Which token feeds table entry `pos` is the same for every action, and a lane always writes
+  // the same entries (pos = lt + e*TS): resolve the mapping once.  src < 0: the entry is a zero.
+  constexpr int EPL = (G::FSTRIDE + TS - 1) / TS;  // table entries per lane per action
+  int src[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int pos = lt + e * TS;
+    int sidx = -1;
+    if (pos < S) {
+      sidx = pos;                                  // u (stored negated for the subtracting modes)
+    } else if (pos > S && pos <= 2 * S) {
+      sidx = S + (pos - S - 1);                    // v
+    } else if (pos >= G::UVLEN && pos < G::FSTRIDE) {
+      int q = pos - G::UVLEN;
+      const int copy = q >= G::WE;
+      q -= copy * G::WE;
+      sidx = 2 * S + (q + copy) % S;               // periodic copies of w (copy 1 shifted by one)
+    }
+    src[e] = sidx;
+  }
+  const bool negate_u = SUB;
   // tile [a0,a0+na): raw tokens (already in LDS when `loaded`) -> int16 tables u,0,v,pad, w-periodic x2
   auto stage = [&](int a0, int na, bool loaded) {
     int head = head0;
@@ -211,22 +232,20 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
       (void)load_raw(a0, na, head);
     }
     __syncthreads();
-    for (int r = lt; r < na * G::FSTRIDE; r += TS) {
-      const int k = r / G::FSTRIDE, pos = r - k * G::FSTRIDE;
+    for (int k = 0; k < na; ++k) {
       const int8_t* t = raw + head + k * (3 * S);
-      int val = 0;
-      if (pos < S) {
-        val = t[pos] - a.shift;
-        if (SUB) val = -val;
-      } else if (pos > S && pos <= 2 * S) {
-        val = t[S + (pos - S - 1)] - a.shift;
-      } else if (pos >= G::UVLEN) {
-        int q = pos - G::UVLEN;
-        const int copy = q >= G::WE;
-        q -= copy * G::WE;
-        val = t[2 * S + (q + copy) % S] - a.shift;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const int pos = lt + e * TS;
+        if (pos < G::FSTRIDE) {
+          int val = 0;
+          if (src[e] >= 0) {
+            val = t[src[e]] - a.shift;
+            if (negate_u && pos < S) val = -val;
+          }
+          F[k * G::FSTRIDE + pos] = static_cast<short>(val);
+        }
       }
-      F[r] = static_cast<short>(val);
     }
     __syncthreads();
   };

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include "../include/tensor_game.h"
+
 #define CK(x)                                                                       \
   do {                                                                              \
     hipError_t e_ = (x);                                                            \
@@ -217,5 +219,35 @@ int main(int argc, char** argv) {
       CK(hipGraphExecDestroy(ge));
       CK(hipGraphDestroy(g));
     }
+  // the product entry point itself (libtensorgame.so), same harness
+  for (int rep = 0; rep < 2; ++rep) {
+    CK(hipMemcpy(st, hs.data(), hs.size(), hipMemcpyHostToDevice));
+    uint8_t* ovf;
+    CK(hipMalloc(&ovf, B));
+    CK(hipMemset(ovf, 0, B));
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < N; ++i)
+      if (tg_step_i8((const int8_t*)st, (int8_t*)st, (const int8_t*)tok, done, rep ? ovf : nullptr, B, 4, 64, 1, s)) {
+        fprintf(stderr, "tg_step_i8: %s\n", tg_last_error());
+        return 1;
+      }
+    CK(hipStreamEndCapture(s, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, s));
+    CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, s));
+    CK(hipGraphLaunch(ge, s));
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("product tg_step_i8 (overflow %s)  graph %.3f us/launch (%.0f GB/s alg)\n", rep ? "tracked" : "NULL",
+           ms * 1e3 / N, B * 141.0 / (ms * 1e-3 / N) / 1e9);
+  }
   return 0;
 }
