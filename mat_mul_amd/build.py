@@ -11,7 +11,7 @@ CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB_PATH = LIB_DIR / "libtensorgame.so"
 SOURCES = [CSRC / "tg_kernels.hip", CSRC / "tg_gen.hip", CSRC / "tg_aux.hip"]
-HEADERS = [CSRC / "tg_device.h", CSRC / "tg_packed.h", PKG.parent / "include" / "tensor_game.h"]
+HEADERS = [CSRC / "tg_device.h", CSRC / "tg_packed.h", CSRC / "tg_rows.h", PKG.parent / "include" / "tensor_game.h"]
 
 
 def _hipcc() -> str:

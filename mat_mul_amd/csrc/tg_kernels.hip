@@ -392,6 +392,7 @@ __global__ __launch_bounds__(kBlock) void team_kernel(ApplyArgs a) {
 }
 
 #include "tg_packed.h"
+#include "tg_rows.h"
 
 // =============================================================================================
 // S = 4 in registers: 4 lanes per game, lane q owns slice i = q (16 bytes = one dwordx4).
@@ -683,6 +684,27 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
                        ldsb, st, a, flim, at);                                                  \
     return check_launch(fn);                                                                    \
   } while (0)
+#define TG_ROWS(S_, TS_)                                                                        \
+  do {                                                                                          \
+    const int64_t blocks = (B + RGeo<S_, TS_>::GPB - 1) / RGeo<S_, TS_>::GPB;                   \
+    if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);              \
+    const int at = a.nact < RGeo<S_, TS_>::ATILE ? a.nact : RGeo<S_, TS_>::ATILE;               \
+    const int ldsb = rows_lds_bytes<S_, TS_, MODE>(at);                                         \
+    (void)hipGetLastError();                                                                    \
+    hipLaunchKernelGGL((rows_kernel<S_, TS_, MODE>), dim3((unsigned)blocks), dim3(kBlock),      \
+                       ldsb, st, a, flim, at);                                                  \
+    return check_launch(fn);                                                                    \
+  } while (0)
+  static const bool no_rows = getenv("TG_NO_ROWS") != nullptr;  // A/B switch for measurements
+  if constexpr (MODE == MANY || MODE == GENF) {
+    // odd S, several actions: each lane owns whole rows (tg_rows.h); the LDS transposition is
+    // amortised over the actions
+    if (al && flim >= 1 && !force_i32 && !no_rows && a.nact >= 3) {
+      if (a.S == 9) TG_ROWS(9, 64);
+      if (a.S == 25) TG_ROWS(25, 256);
+    }
+  }
+#undef TG_ROWS
   if (al && flim >= 1 && !force_i32) {
     if (a.S == 9) TG_PACKED(9, 64);
     if (a.S == 16) TG_PACKED(16, 64);
