@@ -139,7 +139,7 @@ def roofline(B, S, K, event_ms):
     traffic, src = measured_traffic(B, S)
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
-            "kernel": "tg::s4_kernel<STEP>" if S == 4 else f"tg::team_kernel<{S},...,STEP>",
+            "kernel": "tg::s4_kernel<STEP>" if S == 4 else f"tg::packed_kernel<{S},{256 if S == 25 else 64},STEP>",
             "bytes_per_launch": B * bytes_step(S), "avg_launch_us": round(per_launch_s * 1e6, 3)}
 
 
