@@ -50,6 +50,9 @@ typedef void* tg_stream_t; /* hipStream_t */
 
 int tg_abi_version(void);
 const char* tg_last_error(void);
+/* Debug: number of workgroups so far (this process, current device) that left the packed 16-bit
+ * fast path for the exact byte-wise form.  SYNCHRONISES the device; not for hot loops. */
+int tg_debug_fallbacks(uint64_t* count);
 
 /* ---- the env step ------------------------------------------------------------------------- */
 

@@ -27,6 +27,7 @@ _p, _i, _i64, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
 SIGNATURES = {
     "tg_abi_version": [],
     "tg_last_error": [],
+    "tg_debug_fallbacks": [_p],
     "tg_step_i8": [_p, _p, _p, _p, _p, _i64, _i, _i64, _i, _p],
     "tg_step_many_i8": [_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _p],
     "tg_expand_i8": [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i, _p],

@@ -26,6 +26,14 @@ namespace tg {
 
 enum Mode { STEP = 0, MANY = 1, EXPAND = 2, GENF = 3 };
 
+// Debug aid: workgroups of the packed/rows kernels that fell back to the exact byte-wise form
+// (factors too large for the 16-bit path, or an int8 overflow in step_many).  A silent fallback is
+// a 10-50x slowdown, so tests assert that ordinary inputs never take it (tg_debug_fallbacks).
+__device__ unsigned long long g_fallback_workgroups = 0;
+__device__ __forceinline__ void note_fallback() {
+  if (threadIdx.x == 0) atomicAdd(&g_fallback_workgroups, 1ull);
+}
+
 struct ApplyArgs {
   const int8_t* in;      // GENF: unused (state starts at zero)
   int8_t* out;
@@ -668,8 +676,10 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
   }
   // packed int16 path: exact while nact * f^3 <= 32000 for every |factor| <= f (checked on device)
   int flim = 0;
-  {
-    const int64_t n = (MODE == MANY || MODE == GENF) ? a.nact : 1;
+  if constexpr (MODE == MANY) {
+    flim = 5;  // lattice form (tg_packed.h): every |u_i v_j w_l| <= 125 fits one int8 step
+  } else {
+    const int64_t n = (MODE == GENF) ? a.nact : 1;
     while (flim < 31 && static_cast<int64_t>(flim + 1) * (flim + 1) * (flim + 1) * n <= 32000) ++flim;
   }
   static const bool force_i32 = getenv("TG_FORCE_I32") != nullptr;  // A/B switch for measurements
@@ -724,6 +734,15 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
 extern "C" {
 
 int tg_abi_version(void) { return TG_ABI_VERSION; }
+
+int tg_debug_fallbacks(uint64_t* count) {
+  if (!count) return fail(TG_ERR_INVALID, "tg_debug_fallbacks: null pointer");
+  unsigned long long v = 0;
+  hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(tg::g_fallback_workgroups), sizeof(v));
+  if (e != hipSuccess) return fail(TG_ERR_HIP, "tg_debug_fallbacks: %s", hipGetErrorString(e));
+  *count = v;
+  return TG_OK;
+}
 const char* tg_last_error(void) { return g_err; }
 
 int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions, uint8_t* done,

@@ -19,6 +19,16 @@
 // game's tokens decides per workgroup, and games with larger factors run the exact byte-wise
 // 32-bit form (slow_game).  The default vocabulary {-1,0,1} always takes the packed path.
 
+// step_many (MODE == MANY) additionally needs, after EVERY step, the zero test and the int8 range
+// check.  Checking the range costs more than the MACs, so MANY runs on a lattice instead:
+//   x = 256*n + 128 per int16 half, weights pre-multiplied by 256, v_pk_mad_i16 ... clamp.
+// An int8 overflow of n is an int16 saturation of x, which knocks x off the lattice (low byte
+// != 0x80) for good, because every later increment is a multiple of 256.  So the range check is
+// ONE test at the end; a game that fails it is recomputed by the exact byte-wise form before
+// anything is stored.  While on the lattice, "state is zero" <=> OR of all x has zero high bytes.
+// The lattice needs |u_i v_j w_l| <= 127 per action, i.e. |factor| <= 5.
+constexpr uint32_t kLatticeZero = 0x00800080u;
+
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -45,6 +55,18 @@ struct PGeo {
 __device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t d;
   asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// saturating form: the int16 result clamps to [-32768, 32767]
+__device__ __forceinline__ uint32_t pk_mad_i16_sat(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t pk_lshl8_b16(uint32_t a) {
+  uint32_t d;
+  // the shift count is per half: an inline constant 8 would shift the low half only
+  asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(d) : "v"(0x00080008u), "v"(a));
   return d;
 }
 __device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
@@ -82,7 +104,7 @@ constexpr int packed_lds_bytes(int at) {
   using G = PGeo<S, TS>;
   const int tables = G::GPB * at * G::FSTRIDE * 2;
   const int raw = G::GPB * ((at * 3 * S + 8 + 3) & ~3);
-  const int nflag = cmax(MODE == MANY ? TG_MAX_ACTIONS : 4, 3 * G::GPB * at);
+  const int nflag = MODE == MANY ? TG_MAX_ACTIONS + 16 : cmax(4, 3 * G::GPB * at);  // MANY: + recompute byte per team
   return tables + raw + ((nflag + 3) & ~3);
 }
 
@@ -152,7 +174,8 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
         }
       }
     }
-    if (__syncthreads_or(big)) {  // exact byte-wise form, one game at a time (rare; speed is irrelevant)
+    if (__syncthreads_or(big)) {
+      note_fallback();  // exact byte-wise form, one game at a time (rare; speed is irrelevant)
       for (int t = 0; t < G::GPB; ++t) {
         const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
         if (b < a.B) slow_game<MODE>(a, b, flags);
@@ -242,6 +265,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
           if (src[e] >= 0) {
             val = t[src[e]] - a.shift;
             if (negate_u && pos < S) val = -val;
+            if (MODE == MANY && pos >= G::UVLEN) val *= 256;  // lattice weights
           }
           F[k * G::FSTRIDE + pos] = static_cast<short>(val);
         }
@@ -278,7 +302,8 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
         const int uv = mul24_pinned(Fa[rowidx[n][s] & 0xffff], Fa[rowidx[n][s] >> 16]);
         const uint32_t pr = __builtin_amdgcn_perm(static_cast<uint32_t>(uv), static_cast<uint32_t>(uv), 0x05040100u);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) A[n][p] = pk_mad_i16(pr, ws[s][p], A[n][p]);
+        for (int p = 0; p < 8; ++p)
+          A[n][p] = (MODE == MANY) ? pk_mad_i16_sat(pr, ws[s][p], A[n][p]) : pk_mad_i16(pr, ws[s][p], A[n][p]);
       }
     }
   };
@@ -312,7 +337,13 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
   } else if constexpr (MODE == MANY || MODE == GENF) {
     uint32_t A[G::NCH][8];
 #pragma unroll
-    for (int n = 0; n < G::NCH; ++n) unpack_pairs(par[n], A[n]);
+    for (int n = 0; n < G::NCH; ++n) {
+      unpack_pairs(par[n], A[n]);
+      if constexpr (MODE == MANY) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) A[n][p] = pk_add_u16(pk_lshl8_b16(A[n][p]), kLatticeZero);
+      }
+    }
     int done_step = -1;
     if constexpr (MODE == MANY && TS == 256) {
       for (int k = tid; k < a.nact; k += kBlock) flags[k] = 0;
@@ -327,37 +358,74 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
 #pragma unroll
           for (int n = 0; n < G::NCH; ++n)
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-              nz |= A[n][p];
-              ovf |= pk_add_u16(A[n][p], 0x00800080u);
-            }
+            for (int p = 0; p < 8; ++p) nz |= A[n][p];
           if constexpr (TS == 256) {
-            if (nz & 0x00FF00FFu) flags[a0 + k] = 1;
+            if (nz & 0xFF00FF00u) flags[a0 + k] = 1;
           } else {
-            if (!team_any<TS>((nz & 0x00FF00FFu) != 0) && done_step < 0) done_step = a0 + k;
+            if (!team_any<TS>((nz & 0xFF00FF00u) != 0) && done_step < 0) done_step = a0 + k;
           }
         }
       }
     }
-    uint32_t nz = 0;
+    if constexpr (MODE == MANY) {
+      // off the lattice <=> some step overflowed int8: recompute those games exactly, store nothing
+      uint32_t off = 0;
 #pragma unroll
-    for (int n = 0; n < G::NCH; ++n) {
-      const uint4 q = pack_pairs(A[n], nz, ovf);
-      if (live && cv[n]) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * (lt + G::TSA * n), q, ctail[n]);
-    }
-    bool any_ovf;
-    if constexpr (TS == 256) {
-      any_ovf = __syncthreads_or((ovf & 0xFF00FF00u) != 0);  // also orders the flag writes
-      if (MODE == MANY && tid == 0) {
-        for (int k = 0; k < a.nact; ++k)
-          if (!flags[k]) { done_step = k; break; }
+      for (int n = 0; n < G::NCH; ++n)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) off |= (A[n][p] ^ kLatticeZero) & 0x00FF00FFu;
+      bool bad;
+      if constexpr (TS == 256) {
+        bad = __syncthreads_or(off != 0);
+        if (bad) {
+          note_fallback();
+          if (live) slow_game<MODE>(a, g, flags);  // live is workgroup-uniform here (one game per workgroup)
+          return;
+        }
+      } else {
+        bad = team_any<TS>(off != 0);
+        uint8_t* const badF = flags + TG_MAX_ACTIONS;  // one byte per team, past slow_game's per-step flags
+        __syncthreads();
+        if (lt == 0) badF[team] = bad && live;
+        __syncthreads();
+        for (int t = 0; t < G::GPB; ++t)
+          if (badF[t]) {
+            note_fallback();
+            slow_game<MODE>(a, static_cast<int64_t>(blockIdx.x) * G::GPB + t, flags);
+          }
+        if (bad) return;  // after the loop: slow_game needs every lane of the workgroup
       }
+#pragma unroll
+      for (int n = 0; n < G::NCH; ++n) {
+        uint4 q;
+        uint32_t w[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) w[d] = __builtin_amdgcn_perm(A[n][2 * d + 1], A[n][2 * d], 0x07050301u);
+        q = uint4{w[0], w[1], w[2], w[3]};
+        if (live && cv[n]) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * (lt + G::TSA * n), q, ctail[n]);
+      }
+      if constexpr (TS == 256) {
+        __syncthreads();  // orders the per-step flag writes
+        if (tid == 0) {
+          for (int k = 0; k < a.nact; ++k)
+            if (!flags[k]) { done_step = k; break; }
+        }
+      }
+      if (lt == 0 && live) a.done_step[g] = done_step;
     } else {
-      any_ovf = team_any<TS>((ovf & 0xFF00FF00u) != 0);
-    }
-    if (lt == 0 && live) {
-      if constexpr (MODE == MANY) a.done_step[g] = done_step;
-      if (a.overflow && any_ovf) a.overflow[g] = 1;
+      uint32_t nz = 0;
+#pragma unroll
+      for (int n = 0; n < G::NCH; ++n) {
+        const uint4 q = pack_pairs(A[n], nz, ovf);  // GENF: the only range check (sum narrowed once)
+        if (live && cv[n]) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * (lt + G::TSA * n), q, ctail[n]);
+      }
+      bool any_ovf;
+      if constexpr (TS == 256) {
+        any_ovf = __syncthreads_or((ovf & 0xFF00FF00u) != 0);
+      } else {
+        any_ovf = team_any<TS>((ovf & 0xFF00FF00u) != 0);
+      }
+      if (lt == 0 && live && a.overflow && any_ovf) a.overflow[g] = 1;
     }
   } else {  // EXPAND
     uint8_t* const nzF = flags + team * (3 * at);

@@ -35,7 +35,7 @@ constexpr int rows_lds_bytes(int at) {
   const int tables = G::GPB * at * G::TAB_BYTES;
   const int state = G::GPB * G::STATE_BYTES;
   const int raw = G::GPB * ((at * 3 * S + 8 + 15) & ~15);
-  const int nflag = cmax(MODE == MANY ? TG_MAX_ACTIONS : 16, 16);
+  const int nflag = (MODE == MANY ? TG_MAX_ACTIONS : 0) + 16;  // + one "recompute" byte per team
   return tables + state + raw + nflag;
 }
 
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
       }
     }
     if (__syncthreads_or(big)) {
+      note_fallback();
       for (int t = 0; t < G::GPB; ++t) {
         const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
         if (b < a.B) slow_game<MODE>(a, b, flags);
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
 #pragma unroll
   for (int n = 0; n < G::NR; ++n)
 #pragma unroll
-    for (int p = 0; p < G::NP; ++p) acc[n][p] = 0;
+    for (int p = 0; p < G::NP; ++p) acc[n][p] = (MODE == MANY) ? kLatticeZero : 0u;  // MANY: lattice, tg_packed.h
   if constexpr (MODE == MANY) {
     const int8_t* src = a.in + g * a.in_stride;
     for (int c = lt; c < G::NCHUNK; c += TS) {
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
         const int8_t* row = reinterpret_cast<const int8_t*>(st) + (lt + TS * n) * S;
 #pragma unroll
         for (int p = 0; p < G::NP; ++p) {
-          const int lo = row[2 * p];
-          const int hi = (2 * p + 1 < S) ? row[2 * p + 1] : 0;
+          const int lo = row[2 * p] * 256 + 128;
+          const int hi = (2 * p + 1 < S) ? row[2 * p + 1] * 256 + 128 : 128;
           acc[n][p] = __builtin_amdgcn_perm(static_cast<uint32_t>(hi), static_cast<uint32_t>(lo), 0x05040100u);
         }
       }
@@ -197,8 +198,12 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
         const int8_t* t = raw + head + k * (3 * S);
         uint8_t* T = tab + k * G::TAB_BYTES + dst_off;
         int v0 = i0 >= 0 ? t[i0] - a.shift : 0;
-        const int v1 = i1 >= 0 ? t[i1] - a.shift : 0;
+        int v1 = i1 >= 0 ? t[i1] - a.shift : 0;
         if (neg) v0 = -v0;
+        if (MODE == MANY && dword) {  // lattice weights
+          v0 *= 256;
+          v1 *= 256;
+        }
         if (dword)
           *reinterpret_cast<uint32_t*>(T) =
               __builtin_amdgcn_perm(static_cast<uint32_t>(v1), static_cast<uint32_t>(v0), 0x05040100u);
@@ -229,37 +234,68 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
         const int uv = mul24_pinned(ui, vj);
         const uint32_t pr = __builtin_amdgcn_perm(static_cast<uint32_t>(uv), static_cast<uint32_t>(uv), 0x05040100u);
 #pragma unroll
-        for (int p = 0; p < G::NP; ++p) acc[n][p] = pk_mad_i16(pr, wp[p], acc[n][p]);
+        for (int p = 0; p < G::NP; ++p)
+          acc[n][p] = (MODE == MANY) ? pk_mad_i16_sat(pr, wp[p], acc[n][p]) : pk_mad_i16(pr, wp[p], acc[n][p]);
       }
       if constexpr (MODE == MANY) {
         uint32_t nz = 0;
 #pragma unroll
         for (int n = 0; n < G::NR; ++n)
 #pragma unroll
-          for (int p = 0; p < G::NP; ++p) {
-            nz |= acc[n][p];
-            ovf |= pk_add_u16(acc[n][p], 0x00800080u);
-          }
+          for (int p = 0; p < G::NP; ++p) nz |= acc[n][p];
         if constexpr (TS == 256) {
-          if (nz & 0x00FF00FFu) flags[a0 + k] = 1;
+          if (nz & 0xFF00FF00u) flags[a0 + k] = 1;
         } else {
-          if (!team_any<TS>((nz & 0x00FF00FFu) != 0) && done_step < 0) done_step = a0 + k;
+          if (!team_any<TS>((nz & 0xFF00FF00u) != 0) && done_step < 0) done_step = a0 + k;
         }
       }
     }
   }
 
+  // ---- MANY: off the lattice <=> some step overflowed int8 -> exact recompute, nothing stored -------
+  if constexpr (MODE == MANY) {
+    uint32_t off = 0;
+#pragma unroll
+    for (int n = 0; n < G::NR; ++n)
+#pragma unroll
+      for (int p = 0; p < G::NP; ++p) off |= (acc[n][p] ^ kLatticeZero) & 0x00FF00FFu;
+    if constexpr (TS == 256) {
+      if (__syncthreads_or(off != 0)) {
+        note_fallback();
+        if (live) slow_game<MODE>(a, g, flags);
+        return;
+      }
+    } else {
+      const bool bad = team_any<TS>(off != 0);
+      uint8_t* const badF = flags + TG_MAX_ACTIONS;
+      __syncthreads();
+      if (lt == 0) badF[team] = bad && live;
+      __syncthreads();
+      for (int t = 0; t < G::GPB; ++t)
+        if (badF[t]) {
+          note_fallback();
+          slow_game<MODE>(a, static_cast<int64_t>(blockIdx.x) * G::GPB + t, flags);
+        }
+      if (bad) return;
+    }
+  }
+
   // ---- rows -> LDS bytes -> coalesced 16-byte stores ----------------------------------------------
-  if constexpr (MODE == MANY) __syncthreads();  // everyone is done reading rows of `st`? (read before the loop) -- keeps tiles' barriers paired
+  __syncthreads();
 #pragma unroll
   for (int n = 0; n < G::NR; ++n) {
     if (rv[n]) {
       uint8_t* row = st + (lt + TS * n) * S;
 #pragma unroll
       for (int p = 0; p < G::NP; ++p) {
-        ovf |= pk_add_u16(acc[n][p], 0x00800080u);
-        row[2 * p] = static_cast<uint8_t>(acc[n][p]);
-        if (2 * p + 1 < S) row[2 * p + 1] = static_cast<uint8_t>(acc[n][p] >> 16);
+        if constexpr (MODE == MANY) {
+          row[2 * p] = static_cast<uint8_t>(acc[n][p] >> 8);
+          if (2 * p + 1 < S) row[2 * p + 1] = static_cast<uint8_t>(acc[n][p] >> 24);
+        } else {
+          ovf |= pk_add_u16(acc[n][p], 0x00800080u);
+          row[2 * p] = static_cast<uint8_t>(acc[n][p]);
+          if (2 * p + 1 < S) row[2 * p + 1] = static_cast<uint8_t>(acc[n][p] >> 16);
+        }
       }
     }
   }
@@ -274,18 +310,21 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
       }
     }
   }
-  bool any_ovf;
-  if constexpr (TS == 256) {
-    any_ovf = __syncthreads_or((ovf & 0xFF00FF00u) != 0);
-    if (MODE == MANY && tid == 0) {
-      for (int k = 0; k < a.nact; ++k)
-        if (!flags[k]) { done_step = k; break; }
+  if constexpr (MODE == MANY) {
+    if constexpr (TS == 256) {
+      if (tid == 0) {
+        for (int k = 0; k < a.nact; ++k)
+          if (!flags[k]) { done_step = k; break; }
+      }
     }
+    if (lt == 0 && live) a.done_step[g] = done_step;
   } else {
-    any_ovf = team_any<TS>((ovf & 0xFF00FF00u) != 0);
-  }
-  if (lt == 0 && live) {
-    if constexpr (MODE == MANY) a.done_step[g] = done_step;
-    if (a.overflow && any_ovf) a.overflow[g] = 1;
+    bool any_ovf;
+    if constexpr (TS == 256) {
+      any_ovf = __syncthreads_or((ovf & 0xFF00FF00u) != 0);
+    } else {
+      any_ovf = team_any<TS>((ovf & 0xFF00FF00u) != 0);
+    }
+    if (lt == 0 && live && a.overflow && any_ovf) a.overflow[g] = 1;
   }
 }

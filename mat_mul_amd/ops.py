@@ -387,3 +387,12 @@ def slice_rank(state) -> torch.Tensor:
     with torch.cuda.device(state.device):
         call("tg_rank_i32", _ptr(state), _ptr(out), B, S, stride, _stream(state.device))
     return out
+
+
+def debug_fallbacks(device="cuda:0") -> int:
+    """Workgroups that fell back from the packed 16-bit kernels to the exact byte-wise form so far
+    (debug counter; synchronises the device)."""
+    out = C.c_uint64(0)
+    with torch.cuda.device(torch.device(device)):
+        call("tg_debug_fallbacks", C.byref(out))
+    return int(out.value)

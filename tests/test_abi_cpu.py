@@ -20,7 +20,7 @@ def declared_symbols():
 
 def test_header_symbols_all_exported():
     syms = declared_symbols()
-    assert len(syms) == 15
+    assert len(syms) == 16
     assert sorted(_lib.SIGNATURES) == syms                 # the ctypes table covers the header exactly
     lib = C.CDLL(str(_lib.LIB_PATH))
     for s in syms:
@@ -82,6 +82,16 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(8, 2, 2)
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    """No CPU fallback: without the .so the loader raises, and says how to build it."""
+    import importlib
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "libtensorgame.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib._load()
+    import mat_mul_amd.build as b          # the build module itself never needs the library
+    assert b.LIB_PATH.name == "libtensorgame.so"
 
 
 def test_product_never_imports_oracle():

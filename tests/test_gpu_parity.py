@@ -215,6 +215,31 @@ def test_step_many_matches_oracle(S, B, K):
     assert np.array_equal(host(t), want)
 
 
+@pytest.mark.parametrize("S,B,K", [(4, 40, 6), (9, 13, 5), (9, 13, 2), (16, 10, 9), (25, 5, 7), (25, 5, 2), (6, 5, 4)])
+def test_step_many_overflow_and_wide_factors(S, B, K):
+    """step_many where some games overflow int8 mid-way (the lattice form must hand them to the exact
+    path), some use factors too large for the 16-bit path, and some are ordinary."""
+    rng = np.random.default_rng(S * 7 + K)
+    st = rng.integers(-3, 4, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.2, 0.6, 0.2], size=(B, K, 3 * S)).astype(np.int8)
+    st[0::4] = rng.choice([-128, -127, 126, 127], size=st[0::4].shape).astype(np.int8)   # overflow within a few steps
+    ac[0::4] = rng.choice([0, 2], size=ac[0::4].shape)                                  # dense +-1 factors
+    ac[1::4, K // 2] = rng.integers(-6, 9, size=ac[1::4, K // 2].shape)                   # |factor| up to 7
+    st[2::4] = 0
+    st[2::4, 0, 0, 0] = 127                                                              # saturating edge: 127 -/+ 1
+    want, want_ds, want_ovf = O.step_many_i8(st, ac)
+    assert want_ovf[0::4].all() and not want_ovf[3::4].any()
+    for t in (padded(st), dev(st)):
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        out, ds = ops.step_many(t, dev(ac), overflow=ovf)
+        assert np.array_equal(host(out), want), (S, K)
+        assert np.array_equal(host(ds), want_ds) and np.array_equal(host(ovf), want_ovf)
+    t = padded(st)                                                                        # in place
+    ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    ops.step_many(t, dev(ac), out=t, overflow=ovf)
+    assert np.array_equal(host(t), want) and np.array_equal(host(ovf), want_ovf)
+
+
 @pytest.mark.parametrize("S,B,k", [(4, 67, 8), (9, 5, 5), (16, 6, 3), (25, 2, 4), (3, 4, 2), (4, 1, 130)])
 def test_expand_matches_oracle(S, B, k):
     rng = np.random.default_rng(S + 100 * k)
@@ -453,3 +478,23 @@ def test_slice_rank_golden_and_oracle(golden):
     env = TensorGameEnv(3, 4, DEV)
     env.reset()
     assert host(env.rank_reward()).tolist() == [-8, -8, -8]           # <2,2,2>: four slices of rank 2
+
+
+def test_default_vocabulary_never_falls_back():
+    """The packed/rows kernels silently fall back to a 10-50x slower exact form for out-of-range
+    factors or int8 overflow; ordinary inputs ({-1,0,1} and {-2..2} factors, no overflow) must not."""
+    before = ops.debug_fallbacks(DEV)
+    for S, B, R in [(9, 50, 7), (16, 30, 9), (25, 9, 12), (9, 20, 2), (25, 6, 2)]:
+        for values, probs in [((-1, 0, 1), (0.15, 0.7, 0.15)), ((-2, -1, 0, 1, 2), (0.05, 0.1, 0.7, 0.1, 0.05))]:
+            tok, tgt = ops.gen_demos(B, S, R, DEV, values=values, probs=probs, seed=5)
+            st = ops.alloc_states(B, S, DEV)
+            st.copy_(tgt)
+            ops.step(st, tok[:, 0].contiguous())
+            ops.expand(st, tok[:, :2].contiguous())
+            out, ds = ops.step_many(st, tok)
+            assert not bool(out.any())
+    assert ops.debug_fallbacks(DEV) == before
+    st = torch.full((4, 16, 16, 16), 127, dtype=torch.int8, device=DEV)          # forces the overflow path
+    ac = torch.full((4, 3, 48), 0, dtype=torch.int8, device=DEV)                 # factors -1: 127 - (-1) overflows
+    ops.step_many(st, ac)
+    assert ops.debug_fallbacks(DEV) > before
