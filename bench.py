@@ -255,6 +255,28 @@ def main():
                 also.append({"workload": f"S={s2} batch={b2} ({label})", "ok": r2["ok"],
                              "value": round(b2 * k2 / r2["wall_s"], 1), "unit": "steps/s",
                              "roofline": roofline(b2, s2, k2, r2["event_ms"])})
+            # the fused path, labelled separately: K actions per launch, state stays on chip
+            from mat_mul_amd import ops
+            for (s2, b2, k2) in [(4, 65536, 7), (16, 8192, 20)]:
+                tok, tgt = ops.gen_demos(b2, s2, k2, dev, seed=2)
+                st2 = ops.alloc_states(b2, s2, dev)
+                ds = torch.zeros(b2, dtype=torch.int32, device=dev)
+                for _ in range(5):
+                    ops.step_many(tgt, tok, out=st2, done_step=ds)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 50
+                e0.record()
+                for _ in range(reps):
+                    ops.step_many(tgt, tok, out=st2, done_step=ds)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                sec = e0.elapsed_time(e1) * 1e-3 / reps
+                nbytes = b2 * (2 * s2 ** 3 + k2 * 3 * s2 + 4)
+                also.append({"workload": f"FUSED tg_step_many_i8: S={s2} batch={b2}, K={k2} actions per launch "
+                                         f"(bytes per step = (2S^3 + K*3S + 4)/K; not the single-step metric)",
+                             "ok": bool((ds == k2 - 1).all()) and not bool(st2.any()),
+                             "value": round(b2 * k2 / sec, 1), "unit": "steps/s",
+                             "us_per_launch": round(sec * 1e6, 2), "GBps": round(nbytes / sec / 1e9, 1)})
             out["also"] = also
         print(json.dumps(out), flush=True)
     group.close()

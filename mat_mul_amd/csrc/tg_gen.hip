@@ -40,67 +40,75 @@ __device__ __forceinline__ int draw_value(uint32_t d, const Dist& D) {
 constexpr uint32_t kStreamBasis = 0x80000000u;
 constexpr uint32_t kMaxAttempts = 1u << 16;
 
-// One thread per factor vector (game b, term r, x in {u,v,w}).  Counter = (gid_lo, gid_hi,
-// 3r+x, attempt<<8 | block), key = seed: identical to oracle/tensor_game.py::_draw_vector.
-// ST > 0: S is a compile-time constant, the vector lives in registers.  The 256 vectors of a
-// workgroup are contiguous in actions_out, so they are assembled in LDS and written with 16-byte
-// stores (vec16) instead of S-strided byte stores.
-template <int ST>
+// Factor vectors (game b, term r, x in {u,v,w}).  Counter = (gid_lo, gid_hi, 3r+x,
+// attempt<<8 | block), key = seed: identical to oracle/tensor_game.py::_draw_vector.
+// ST > 0: S is a compile-time constant, the vector lives in registers.
+// Rejection sampling diverges: at S=4 a vector is rejected with probability 0.24, and a wavefront
+// that gives each lane ONE vector runs max-over-64-lanes attempts (about 3.9 instead of 1.3).  So a
+// lane owns M vectors (idx = base + lane + 256*m) and walks them in ONE flat loop -- every trip is
+// one attempt for whatever vector the lane is on -- and the rejections average out over M.
+// The M*256 vectors of a workgroup are contiguous in actions_out: they are assembled in LDS and
+// written with 16-byte stores.
+template <int ST, int M>
 __global__ __launch_bounds__(kBlock) void gen_tokens_kernel(int8_t* actions_out, uint8_t* overflow, int64_t B,
                                                             int Srt, int R, Dist D, int shift, uint64_t seed,
                                                             uint64_t gid0, const int8_t* basis, int vec16) {
   constexpr int SMAX = ST ? ST : TG_MAX_S;
   constexpr int NBLK = (SMAX + 3) / 4;
-  __shared__ __attribute__((aligned(16))) int8_t stage[kBlock * SMAX];
+  __shared__ __attribute__((aligned(16))) int8_t stage[kBlock * M * SMAX];
   const int S = ST ? ST : Srt;
   const int64_t nvec = B * R * 3;
   const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
-  const int64_t nround = (nvec + static_cast<int64_t>(gridDim.x) * kBlock - 1) / (static_cast<int64_t>(gridDim.x) * kBlock);
+  const int64_t per_wg = static_cast<int64_t>(kBlock) * M;
+  const int64_t nround = (nvec + gridDim.x * per_wg - 1) / (gridDim.x * per_wg);
+  const uint32_t R3 = static_cast<uint32_t>(3 * R);
   for (int64_t it = 0; it < nround; ++it) {
-    const int64_t base = (it * gridDim.x + blockIdx.x) * kBlock;  // first vector of this workgroup
-    const int64_t idx = base + threadIdx.x;
-    const bool live = idx < nvec;
-    int f[SMAX];
-    int bad = 0;
-    int64_t b = 0;
-    if (live) {
-      // 64-bit division once per workgroup on the scalar unit, 32-bit per lane
-      const int64_t b0 = base / (3 * R);
-      const uint32_t within = static_cast<uint32_t>(base - b0 * 3 * R) + threadIdx.x;
-      const uint32_t db = within / static_cast<uint32_t>(3 * R);
-      b = b0 + db;
-      const int sub = static_cast<int>(within - db * static_cast<uint32_t>(3 * R));  // 3r + x
+    const int64_t base = (it * gridDim.x + blockIdx.x) * per_wg;  // first vector of this workgroup
+    const int64_t b0 = base / R3;                                  // 64-bit division on the scalar unit
+    const uint32_t within0 = static_cast<uint32_t>(base - b0 * R3);
+    int m = 0;
+    uint32_t attempt = 0;
+    while (m < M) {
+      const int64_t idx = base + threadIdx.x + static_cast<int64_t>(kBlock) * m;
+      if (idx >= nvec) break;
+      const uint32_t within = within0 + threadIdx.x + kBlock * m;
+      const uint32_t db = within / R3;
+      const int64_t b = b0 + db;
+      const int sub = static_cast<int>(within - db * R3);  // 3r + x
       const uint64_t gid = gid0 + static_cast<uint64_t>(b);
-      for (uint32_t attempt = 0;; ++attempt) {
-        bool any = false;
+      int f[SMAX];
+      bool any = false;
 #pragma unroll
-        for (int q = 0; q < NBLK; ++q) {
-          if (4 * q < S) {
-            const U4 o = philox4x32_10(U4{static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
-                                          static_cast<uint32_t>(sub), (attempt << 8) | static_cast<uint32_t>(q)},
-                                       k0, k1);
-            const uint32_t d[4] = {o.x, o.y, o.z, o.w};
+      for (int q = 0; q < NBLK; ++q) {
+        if (4 * q < S) {
+          const U4 o = philox4x32_10(U4{static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
+                                        static_cast<uint32_t>(sub), (attempt << 8) | static_cast<uint32_t>(q)},
+                                     k0, k1);
+          const uint32_t d[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const int e = 4 * q + t;
-              if (e < SMAX) {
-                f[e] = (e < S) ? draw_value(d[t], D) : 0;
-                any |= f[e] != 0;
-              }
+          for (int t = 0; t < 4; ++t) {
+            const int e = 4 * q + t;
+            if (e < SMAX) {
+              f[e] = (e < S) ? draw_value(d[t], D) : 0;
+              any |= f[e] != 0;
             }
           }
         }
-        if (any || attempt + 1 >= kMaxAttempts) break;
       }
-      int8_t* dst = stage + threadIdx.x * S;
+      if (!any && attempt + 1 < kMaxAttempts) {
+        ++attempt;
+        continue;
+      }
+      int bad = 0;
+      int8_t* dst = stage + (threadIdx.x + kBlock * m) * S;
       if (basis) {
         const int x = sub % 3;
-        const int8_t* M = basis + (b * 3 + x) * S * S;
+        const int8_t* Mx = basis + (b * 3 + x) * S * S;
         for (int a = 0; a < S; ++a) {
           int acc = 0;
 #pragma unroll
           for (int i = 0; i < SMAX; ++i)
-            if (i < S) acc += M[a * S + i] * f[i];
+            if (i < S) acc += Mx[a * S + i] * f[i];
           const int tokv = acc + shift;
           bad |= tokv + 128;
           dst[a] = static_cast<int8_t>(tokv);
@@ -115,14 +123,16 @@ __global__ __launch_bounds__(kBlock) void gen_tokens_kernel(int8_t* actions_out,
           }
       }
       if (overflow && (bad & ~255)) overflow[b] = 1;
+      ++m;
+      attempt = 0;
     }
     __syncthreads();
     // the workgroup's vectors are the contiguous bytes [base*S, base*S + nlive*S) of actions_out
-    const int64_t nlive = min(static_cast<int64_t>(kBlock), nvec - base);
+    const int64_t nlive = min(per_wg, nvec - base);
     const int nbytes = nlive > 0 ? static_cast<int>(nlive) * S : 0;
     int8_t* out = actions_out + base * S;
     int body = 0;
-    if (vec16 && ((kBlock * S) % 16 == 0)) {
+    if (vec16) {
       body = nbytes & ~15;
       for (int o = 16 * threadIdx.x; o < body; o += 16 * kBlock)
         *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(stage + o);
@@ -276,18 +286,28 @@ int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, 
   if (!target_out || !actions_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
   const int64_t nvec = B * R * 3;
   const int vec16 = (reinterpret_cast<uintptr_t>(actions_out) & 15) == 0;
-  const dim3 grid(grid_for((nvec + tg::kBlock - 1) / tg::kBlock > 16384 ? 16384 : (nvec + tg::kBlock - 1) / tg::kBlock));
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();
-#define TG_GT(ST)                                                                                     \
-  hipLaunchKernelGGL(tg::gen_tokens_kernel<ST>, grid, dim3(tg::kBlock), 0, st, actions_out, overflow, \
-                     B, S, R, D, shift, seed, game_id_offset, basis, vec16)
+#define TG_GT(ST, M)                                                                                      \
+  do {                                                                                                    \
+    const int64_t wgs = (nvec + tg::kBlock * M - 1) / (tg::kBlock * M);                                   \
+    hipLaunchKernelGGL((tg::gen_tokens_kernel<ST, M>), dim3(grid_for(wgs > 16384 ? 16384 : wgs)),        \
+                       dim3(tg::kBlock), 0, st, actions_out, overflow, B, S, R, D, shift, seed,           \
+                       game_id_offset, basis, vec16);                                                     \
+  } while (0)
   switch (S) {
-    case 4: TG_GT(4); break;
-    case 9: TG_GT(9); break;
-    case 16: TG_GT(16); break;
-    case 25: TG_GT(25); break;
-    default: TG_GT(0); break;
+    case 4:  // 24 % of the draws are rejected: several vectors per lane, as long as the chip stays full
+      if (nvec >= (int64_t)tg::kBlock * 16 * 2048) TG_GT(4, 16);
+      else if (nvec >= (int64_t)tg::kBlock * 4 * 1024) TG_GT(4, 4);
+      else TG_GT(4, 1);
+      break;
+    case 9:  // 4 %
+      if (nvec >= (int64_t)tg::kBlock * 4 * 2048) TG_GT(9, 4);
+      else TG_GT(9, 1);
+      break;
+    case 16: TG_GT(16, 1); break;
+    case 25: TG_GT(25, 1); break;
+    default: TG_GT(0, 1); break;
   }
 #undef TG_GT
   if (int rc = launched(fn)) return rc;
@@ -315,9 +335,9 @@ int tg_change_basis_i8(const int8_t* state_in, const int32_t* basis, int8_t* sta
   const char* fn = "tg_change_basis_i8";
   if (B < 0 || S < 1 || S > TG_MAX_S || game_stride_bytes < (int64_t)S * S * S)
     return tg_internal_fail(TG_ERR_INVALID, "%s: bad B/S/stride", fn);
+  if (B && state_in && state_in == state_out) return tg_internal_fail(TG_ERR_INVALID, "%s: in-place is not supported", fn);
   if (B == 0) return TG_OK;
   if (!state_in || !basis || !state_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
-  if (state_in == state_out) return tg_internal_fail(TG_ERR_INVALID, "%s: in-place is not supported", fn);
   const size_t lds = static_cast<size_t>(S) * S * (S + 1) * sizeof(int);
   if (lds > 160 * 1024) return tg_internal_fail(TG_ERR_UNSUPPORTED, "%s: S=%d needs %zu B of LDS", fn, S, lds);
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -778,7 +778,7 @@ int tg_expand_i8(const int8_t* state_in, int8_t* state_out, const int8_t* action
     return fail(TG_ERR_INVALID, "tg_expand_i8: k=%d outside [1,%d]", k, TG_MAX_ACTIONS);
   if (B && (!state_in || !state_out || !actions || !done))
     return fail(TG_ERR_INVALID, "tg_expand_i8: null pointer");
-  if (state_in == state_out) return fail(TG_ERR_INVALID, "tg_expand_i8: in-place expansion is not defined");
+  if (B && state_in == state_out) return fail(TG_ERR_INVALID, "tg_expand_i8: in-place expansion is not defined");
   tg::ApplyArgs a{state_in, state_out, actions, done, nullptr, changed, overflow, B,
                   in_stride_bytes, out_stride_bytes, S, k, shift};
   return launch_apply<tg::EXPAND>("tg_expand_i8", a, static_cast<hipStream_t>(stream));

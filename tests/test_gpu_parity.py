@@ -315,9 +315,9 @@ def test_synthetic_demos_class_matches_reference_framing(golden):
 
 
 # ------------------------------------------------------------------ change of basis (A12, parity unpinned: invariants)
-@pytest.mark.parametrize("S", [4, 9, 16, 25, 6])
+@pytest.mark.parametrize("S", [4, 9, 16, 25, 6, 32])
 def test_basis(S):
-    B = 7
+    B = 7 if S < 32 else 2   # S=32 needs 135 KB of LDS per workgroup (dynamic LDS above 64 KB)
     bp = (0.2, 0.6, 0.2) if S <= 9 else (0.03, 0.94, 0.03)
     thr = O.categorical_thresholds(bp)
     P_o, L_o, U_o = O.sample_basis(B, S, thr, (-1, 0, 1), seed=21, game_id_offset=5)
@@ -498,3 +498,46 @@ def test_default_vocabulary_never_falls_back():
     ac = torch.full((4, 3, 48), 0, dtype=torch.int8, device=DEV)                 # factors -1: 127 - (-1) overflows
     ops.step_many(st, ac)
     assert ops.debug_fallbacks(DEV) > before
+
+
+# ------------------------------------------------------------------ edge cases: empty batch, maximum action counts
+def test_empty_batch_is_a_noop():
+    for S in (4, 16, 25, 7):
+        st = ops.alloc_states(0, S, DEV)
+        ac = torch.empty((0, 3 * S), dtype=torch.int8, device=DEV)
+        out, done = ops.step(st, ac)
+        assert out.shape == (0, S, S, S) and done.shape == (0,)
+        out, ds = ops.step_many(st, torch.empty((0, 5, 3 * S), dtype=torch.int8, device=DEV))
+        assert ds.shape == (0,)
+        kids, d, c = ops.expand(st, torch.empty((0, 3, 3 * S), dtype=torch.int8, device=DEV))
+        assert kids.shape == (0, 3, S, S, S)
+        assert ops.done(st).shape == (0,) and ops.state_hash(st).shape == (0,) and ops.slice_rank(st).shape == (0,)
+        tok, tgt = ops.gen_demos(0, S, 4, DEV)
+        assert tok.shape == (0, 4, 3 * S) and tgt.shape == (0, S, S, S)
+    env = TensorGameEnv(0, 4, DEV)
+    env.reset()
+    assert env.model_input()[0].shape == (0, 1, 4, 4, 4)
+
+
+@pytest.mark.parametrize("S,B", [(4, 3), (9, 2), (16, 2), (25, 1), (6, 1)])
+def test_maximum_action_counts(S, B):
+    """K = k = R = TG_MAX_ACTIONS (4096) and counts that straddle the LDS action tiles."""
+    from mat_mul_amd._lib import TG_MAX_ACTIONS
+    rng = np.random.default_rng(S)
+    for K in (TG_MAX_ACTIONS, 65, 129):
+        ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, K, 3 * S)).astype(np.int8)
+        tgt_o, ovf_o = O.gen_from_factors_i8(ac)
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        tgt = ops.gen_from_factors(dev(ac), S, overflow=ovf)
+        assert np.array_equal(host(tgt), tgt_o) and np.array_equal(host(ovf), ovf_o)
+        st = rng.integers(-1, 2, size=(B, S, S, S)).astype(np.int8)
+        want, want_ds, want_ovf = O.step_many_i8(st, ac)
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        out, ds = ops.step_many(padded(st), dev(ac), overflow=ovf)
+        assert np.array_equal(host(out), want) and np.array_equal(host(ds), want_ds) and np.array_equal(host(ovf), want_ovf)
+        if K <= 129 or S <= 9:
+            kids_o, done_o, chg_o, _ = O.expand_i8(st, ac)
+            kids, done, chg = ops.expand(padded(st), dev(ac))
+            assert np.array_equal(host(kids), kids_o) and np.array_equal(host(done), done_o) and np.array_equal(host(chg), chg_o)
+    with pytest.raises(mat_mul_amd.TensorGameError, match="outside"):
+        ops.step_many(padded(st), torch.zeros((B, TG_MAX_ACTIONS + 1, 3 * S), dtype=torch.int8, device=DEV))
