@@ -32,6 +32,50 @@ constexpr uint32_t kLatticeZero = 0x00800080u;
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// ---- token loading shared by the packed and rows kernels ---------------------------------------
+// A game's tokens are `nbytes` contiguous int8 at `src` (any alignment).  They are fetched with
+// aligned dword loads: the dword that holds a valid byte never crosses a page, so the <= 3 stray
+// bytes at either end are safe to read and are ignored.  All of a lane's loads are independent:
+// one memory latency per call.  Returns whether any factor (token - shift) exceeds +-flim.
+// With `raw` != nullptr the dwords are also copied to LDS; the first valid byte is raw[head].
+template <int TS>
+__device__ __forceinline__ int load_tokens_checked(const int8_t* src, int nbytes, int8_t* raw, int lt, int shift,
+                                                   int flim, int& head) {
+  const uintptr_t A = reinterpret_cast<uintptr_t>(src);
+  head = static_cast<int>(A & 3);
+  const uint32_t* A4 = reinterpret_cast<const uint32_t*>(A - head);
+  const int ndw = (head + nbytes + 3) >> 2;
+  uint32_t* rawdw = reinterpret_cast<uint32_t*>(raw);
+  int big = 0;
+#pragma unroll 4
+  for (int idx = lt; idx < ndw; idx += TS) {
+    const uint32_t x = A4[idx];
+    if (raw) rawdw[idx] = x;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int o = 4 * idx + t - head;
+      const int f = sbyte(x, t) - shift;
+      big |= (o >= 0 && o < nbytes) && ((f > flim) | (f < -flim));
+    }
+  }
+  return big;
+}
+
+// Do all factors of this workgroup's games fit the 16-bit path?  Single tile (nact <= at): the
+// check rides on the tile's own raw load (left in LDS, head0 set).  Several tiles: every token is
+// scanned first, because the state must not be touched before the decision.  Workgroup-uniform.
+template <int TS>
+__device__ __forceinline__ bool factors_too_large(const int8_t* tok, int nact, int at, int tok_per_action,
+                                                  int8_t* raw, int lt, int shift, int flim, int& head0) {
+  int big, hd;
+  if (nact <= at) {
+    big = load_tokens_checked<TS>(tok, nact * tok_per_action, raw, lt, shift, flim, head0);
+  } else {
+    big = load_tokens_checked<TS>(tok, nact * tok_per_action, nullptr, lt, shift, flim, hd);
+  }
+  return __syncthreads_or(big) != 0;
+}
+
 template <int S, int TS>
 struct PGeo {
   static constexpr int N = S * S * S;
@@ -125,63 +169,19 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
   const int8_t* const tok = a.actions + g * a.nact * (3 * S);
   int8_t* const raw = raw_all + team * raw_stride;
 
-  // Raw tokens of actions [a0, a0+na) -> LDS with aligned dword loads (the dword that holds a
-  // valid byte never crosses a page, so the <= 3 stray bytes at either end are safe to read and
-  // are ignored).  All of a lane's loads are independent: one memory latency per tile.
-  // Returns whether any factor of the tile exceeds +-flim.
-  auto load_raw = [&](int a0, int na, int& head) -> int {
-    const uintptr_t A = reinterpret_cast<uintptr_t>(tok + a0 * (3 * S));
-    head = static_cast<int>(A & 3);
-    const uint32_t* A4 = reinterpret_cast<const uint32_t*>(A - head);
-    const int nbytes = na * 3 * S, ndw = (head + nbytes + 3) >> 2;
-    uint32_t* rawdw = reinterpret_cast<uint32_t*>(raw);
-    int big = 0;
-#pragma unroll 4
-    for (int idx = lt; idx < ndw; idx += TS) {
-      const uint32_t x = A4[idx];
-      rawdw[idx] = x;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int o = 4 * idx + t - head;
-        const int f = sbyte(x, t) - a.shift;
-        big |= (o >= 0 && o < nbytes) && ((f > flim) | (f < -flim));
-      }
-    }
-    return big;
+  auto load_raw = [&](int a0, int na, int& head) {  // tokens of actions [a0,a0+na) -> LDS, unchecked
+    (void)load_tokens_checked<TS>(tok + a0 * (3 * S), na * 3 * S, raw, lt, a.shift, 0x7fffffff, head);
   };
 
-  // ---- do all factors of this workgroup's games fit the 16-bit path? ---------------------------
-  // Single tile (nact <= at): the range check rides on the tile's own raw load below.
-  // Several tiles: prescan every token first (the state must not be touched before the decision).
   int head0 = 0;
-  {
-    int big = 0;
-    if (a.nact <= at) {
-      big = load_raw(0, a.nact, head0);
-    } else {
-      const uintptr_t A = reinterpret_cast<uintptr_t>(tok);
-      const int hd = static_cast<int>(A & 3);
-      const uint32_t* A4 = reinterpret_cast<const uint32_t*>(A - hd);
-      const int nbytes = a.nact * 3 * S, ndw = (hd + nbytes + 3) >> 2;
-#pragma unroll 4
-      for (int idx = lt; idx < ndw; idx += TS) {
-        const uint32_t x = A4[idx];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int o = 4 * idx + t - hd;
-          const int f = sbyte(x, t) - a.shift;
-          big |= (o >= 0 && o < nbytes) && ((f > flim) | (f < -flim));
-        }
-      }
+  if (factors_too_large<TS>(tok, a.nact, at, 3 * S, raw, lt, a.shift, flim, head0)) {
+    // exact byte-wise form, one game at a time (rare; speed is irrelevant)
+    note_fallback();
+    for (int t = 0; t < G::GPB; ++t) {
+      const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
+      if (b < a.B) slow_game<MODE>(a, b, flags);
     }
-    if (__syncthreads_or(big)) {
-      note_fallback();  // exact byte-wise form, one game at a time (rare; speed is irrelevant)
-      for (int t = 0; t < G::GPB; ++t) {
-        const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
-        if (b < a.B) slow_game<MODE>(a, b, flags);
-      }
-      return;
-    }
+    return;
   }
 
   // ---- lane geometry ----------------------------------------------------------------------------
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
     int head = head0;
     if (!loaded) {
       __syncthreads();  // previous tile's tables and raw bytes are no longer read
-      (void)load_raw(a0, na, head);
+      load_raw(a0, na, head);
     }
     __syncthreads();
     for (int k = 0; k < na; ++k) {

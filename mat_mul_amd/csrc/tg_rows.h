@@ -61,56 +61,18 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
   uint8_t* const tab = tab_all + team * (at * G::TAB_BYTES);
   uint8_t* const st = state_all + team * G::STATE_BYTES;
 
-  auto load_raw = [&](int a0, int na, int& head) -> int {  // as in packed_kernel
-    const uintptr_t A = reinterpret_cast<uintptr_t>(tok + a0 * (3 * S));
-    head = static_cast<int>(A & 3);
-    const uint32_t* A4 = reinterpret_cast<const uint32_t*>(A - head);
-    const int nbytes = na * 3 * S, ndw = (head + nbytes + 3) >> 2;
-    uint32_t* rawdw = reinterpret_cast<uint32_t*>(raw);
-    int big = 0;
-#pragma unroll 4
-    for (int idx = lt; idx < ndw; idx += TS) {
-      const uint32_t x = A4[idx];
-      rawdw[idx] = x;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int o = 4 * idx + t - head;
-        const int f = sbyte(x, t) - a.shift;
-        big |= (o >= 0 && o < nbytes) && ((f > flim) | (f < -flim));
-      }
-    }
-    return big;
+  auto load_raw = [&](int a0, int na, int& head) {  // tokens of actions [a0,a0+na) -> LDS, unchecked
+    (void)load_tokens_checked<TS>(tok + a0 * (3 * S), na * 3 * S, raw, lt, a.shift, 0x7fffffff, head);
   };
 
   int head0 = 0;
-  {
-    int big = 0;
-    if (a.nact <= at) {
-      big = load_raw(0, a.nact, head0);
-    } else {
-      const uintptr_t A = reinterpret_cast<uintptr_t>(tok);
-      const int hd = static_cast<int>(A & 3);
-      const uint32_t* A4 = reinterpret_cast<const uint32_t*>(A - hd);
-      const int nbytes = a.nact * 3 * S, ndw = (hd + nbytes + 3) >> 2;
-#pragma unroll 4
-      for (int idx = lt; idx < ndw; idx += TS) {
-        const uint32_t x = A4[idx];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int o = 4 * idx + t - hd;
-          const int f = sbyte(x, t) - a.shift;
-          big |= (o >= 0 && o < nbytes) && ((f > flim) | (f < -flim));
-        }
-      }
+  if (factors_too_large<TS>(tok, a.nact, at, 3 * S, raw, lt, a.shift, flim, head0)) {
+    note_fallback();
+    for (int t = 0; t < G::GPB; ++t) {
+      const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
+      if (b < a.B) slow_game<MODE>(a, b, flags);
     }
-    if (__syncthreads_or(big)) {
-      note_fallback();
-      for (int t = 0; t < G::GPB; ++t) {
-        const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
-        if (b < a.B) slow_game<MODE>(a, b, flags);
-      }
-      return;
-    }
+    return;
   }
 
   // ---- lane geometry: rows r = lt + TS*n ----------------------------------------------------------
@@ -190,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
     int head = head0;
     if (!loaded) {
       __syncthreads();
-      (void)load_raw(a0, na, head);
+      load_raw(a0, na, head);
     }
     __syncthreads();
     if (dst_off >= 0) {

@@ -541,3 +541,42 @@ def test_maximum_action_counts(S, B):
             assert np.array_equal(host(kids), kids_o) and np.array_equal(host(done), done_o) and np.array_equal(host(chg), chg_o)
     with pytest.raises(mat_mul_amd.TensorGameError, match="outside"):
         ops.step_many(padded(st), torch.zeros((B, TG_MAX_ACTIONS + 1, 3 * S), dtype=torch.int8, device=DEV))
+
+
+AB_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from mat_mul_amd import ops
+from oracle import tensor_game as O
+rng = np.random.default_rng(1)
+for S, B, K in [(9, 9, 6), (16, 6, 5), (25, 3, 7)]:
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, K, 3 * S)).astype(np.int8)
+    t = ops.alloc_states(B, S, "cuda:0"); t.copy_(torch.from_numpy(st))
+    a = torch.from_numpy(ac).cuda()
+    w, wd, _ = O.step_i8(st, ac[:, 0])
+    o, d = ops.step(t, a[:, 0].contiguous())
+    assert np.array_equal(o.cpu().numpy(), w) and np.array_equal(d.cpu().numpy(), wd)
+    w, wds, _ = O.step_many_i8(st, ac)
+    o, ds = ops.step_many(t, a)
+    assert np.array_equal(o.cpu().numpy(), w) and np.array_equal(ds.cpu().numpy(), wds)
+    wk, wdn, wch, _ = O.expand_i8(st, ac)
+    k, dn, ch = ops.expand(t, a)
+    assert np.array_equal(k.cpu().numpy(), wk) and np.array_equal(dn.cpu().numpy(), wdn) and np.array_equal(ch.cpu().numpy(), wch)
+    assert np.array_equal(ops.gen_from_factors(a, S).cpu().numpy(), O.gen_from_factors_i8(ac)[0])
+print("AB_OK")
+'''
+
+
+@pytest.mark.parametrize("env_name", ["TG_FORCE_I32", "TG_NO_ROWS"])
+def test_ab_switch_paths_stay_exact(env_name, tmp_path):
+    """The measurement switches (32-bit cursor kernels; packed chunks instead of rows) select
+    kernels that the default dispatch no longer uses -- they must stay bit-exact too."""
+    import os, subprocess, sys
+    from pathlib import Path
+    script = tmp_path / "ab.py"
+    script.write_text(AB_SCRIPT)
+    root = str(Path(__file__).resolve().parent.parent)
+    env = dict(os.environ, **{env_name: "1"})
+    res = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "AB_OK" in res.stdout, res.stderr[-2000:]
