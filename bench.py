@@ -211,6 +211,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    # Rehearsal switches (not used by the driver): TG_BENCH_SHARE_GPU=1 maps every rank onto the
+    # GPUs that exist (N ranks on a 1-GPU box), TG_BENCH_BACKEND=gloo replaces the RCCL control plane.
+    if os.environ.get("TG_BENCH_SHARE_GPU"):
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -218,7 +222,7 @@ def main():
     from mat_mul_amd import shard_range
     from mat_mul_amd.sharding import RankGroup
 
-    group = RankGroup("nccl", dev)  # control plane only: barrier + max of the elapsed time
+    group = RankGroup(os.environ.get("TG_BENCH_BACKEND", "nccl"), dev)  # control plane only: barrier + max of the elapsed time
 
     S = args.dim
     Bg = args.batch or {4: 65536, 16: 8192, 25: 4096, 9: 32768}.get(S, 4096)

@@ -169,21 +169,8 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
   const int8_t* const tok = a.actions + g * a.nact * (3 * S);
   int8_t* const raw = raw_all + team * raw_stride;
 
-  auto load_raw = [&](int a0, int na, int& head) {  // tokens of actions [a0,a0+na) -> LDS, unchecked
-    (void)load_tokens_checked<TS>(tok + a0 * (3 * S), na * 3 * S, raw, lt, a.shift, 0x7fffffff, head);
-  };
-
-  int head0 = 0;
-  if (factors_too_large<TS>(tok, a.nact, at, 3 * S, raw, lt, a.shift, flim, head0)) {
-    // exact byte-wise form, one game at a time (rare; speed is irrelevant)
-    note_fallback();
-    for (int t = 0; t < G::GPB; ++t) {
-      const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
-      if (b < a.B) slow_game<MODE>(a, b, flags);
-    }
-    return;
-  }
-
+  // Geometry and the state loads come FIRST: the loads do not depend on the tokens, so their
+  // latency overlaps the token fetch and the fallback decision below instead of following it.
   // ---- lane geometry ----------------------------------------------------------------------------
   const bool active = lt < G::TSA;
   const int l0 = (16 * lt) % S;
@@ -223,6 +210,21 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
     par[n] = uint4{0, 0, 0, 0};
     if (MODE != GENF && cv[n])
       par[n] = load_chunk<G::TAIL>(a.in + g * a.in_stride + 16 * (lt + G::TSA * n), ctail[n]);
+  }
+
+  auto load_raw = [&](int a0, int na, int& head) {  // tokens of actions [a0,a0+na) -> LDS, unchecked
+    (void)load_tokens_checked<TS>(tok + a0 * (3 * S), na * 3 * S, raw, lt, a.shift, 0x7fffffff, head);
+  };
+
+  int head0 = 0;
+  if (factors_too_large<TS>(tok, a.nact, at, 3 * S, raw, lt, a.shift, flim, head0)) {
+    // exact byte-wise form, one game at a time (rare; speed is irrelevant)
+    note_fallback();
+    for (int t = 0; t < G::GPB; ++t) {
+      const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
+      if (b < a.B) slow_game<MODE>(a, b, flags);
+    }
+    return;
   }
 
   short* const F = lds + team * (at * G::FSTRIDE);

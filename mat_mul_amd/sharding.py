@@ -46,7 +46,8 @@ class RankGroup:
             return tuple(float(v) for v in values)
         import torch
 
-        t = torch.tensor(values, dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        on_gpu = self.device is not None and self.dist.get_backend() == "nccl"
+        t = torch.tensor(values, dtype=torch.float64, device=self.device if on_gpu else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return tuple(float(x) for x in t)
 
