@@ -580,3 +580,50 @@ def test_ab_switch_paths_stay_exact(env_name, tmp_path):
     env = dict(os.environ, **{env_name: "1"})
     res = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "AB_OK" in res.stdout, res.stderr[-2000:]
+
+
+def test_randomized_differential():
+    """Seeded random configurations -- S, batch, game stride padding, byte offset of the buffer,
+    vocabulary, shift, action count, mode -- every one compared bit for bit with the oracle."""
+    rng = np.random.default_rng(20261004)
+    vocabularies = [((0, 1, 2), 1), ((1, 2, 3), 2), ((0, 1, 2, 3, 4), 2), ((-1, 0, 1), 0), (tuple(range(-4, 7)), 1)]
+    n_cases = 0
+    for case in range(120):
+        S = int(rng.choice([1, 2, 3, 4, 4, 5, 7, 8, 9, 9, 12, 16, 16, 25, 25, 32]))
+        B = int(rng.integers(1, 24 if S <= 16 else 6))
+        K = int(rng.integers(1, 12))
+        toks, shift = vocabularies[int(rng.integers(len(vocabularies)))]
+        N = S ** 3
+        pad = int(rng.choice([0, 0, 16 - N % 16 if N % 16 else 0, 3, 48]))
+        offset = int(rng.choice([0, 0, 0, 16, 5]))
+        stride = N + pad
+        st = rng.integers(-3, 4, size=(B, S, S, S)).astype(np.int8)
+        ac = rng.choice(toks, size=(B, K, 3 * S)).astype(np.int8)
+        buf = torch.zeros(B * stride + offset + 64, dtype=torch.int8, device=DEV)
+        t = buf[offset:offset + B * stride].view(B, stride)[:, :N].unflatten(1, (S, S, S))
+        t.copy_(dev(st))
+        mode = case % 4
+        ovf = torch.zeros((B,), dtype=torch.uint8, device=DEV)
+        if mode == 0:
+            want, wd, wo = O.step_i8(st, ac[:, 0], shift)
+            out, d = ops.step(t, dev(ac[:, 0]), overflow=ovf, shift=shift)
+            ok = np.array_equal(host(out), want) and np.array_equal(host(d), wd) and np.array_equal(host(ovf), wo)
+        elif mode == 1:
+            want, wds, wo = O.step_many_i8(st, ac, shift)
+            out, ds = ops.step_many(t, dev(ac), overflow=ovf, shift=shift)
+            ok = np.array_equal(host(out), want) and np.array_equal(host(ds), wds) and np.array_equal(host(ovf), wo)
+        elif mode == 2:
+            wk, wd, wc, wo = O.expand_i8(st, ac, shift)
+            ovk = torch.zeros((B, K), dtype=torch.uint8, device=DEV)
+            kids, d, c = ops.expand(t, dev(ac), overflow=ovk, shift=shift)
+            ok = (np.array_equal(host(kids), wk) and np.array_equal(host(d), wd) and np.array_equal(host(c), wc)
+                  and np.array_equal(host(ovk), wo))
+        else:
+            want, wo = O.gen_from_factors_i8(ac, shift)
+            out = ops.gen_from_factors(dev(ac), S, overflow=ovf, shift=shift)
+            ok = np.array_equal(host(out), want) and np.array_equal(host(ovf), wo)
+        assert ok, dict(case=case, S=S, B=B, K=K, shift=shift, pad=pad, offset=offset, mode=mode, toks=toks)
+        assert np.array_equal(host(t), st) or mode == 3, "inputs must be untouched"
+        assert np.array_equal(host(ops.state_hash(t)).view(np.uint64), O.state_hash(st))
+        n_cases += 1
+    assert n_cases == 120
