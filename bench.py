@@ -182,7 +182,25 @@ def cpu_baseline(B, S, budget_s=12.0):
         s1, d1 = P.env_step(s1, a1)
         m += 1
     single = m / (time.perf_counter() - t1)
+    # the plain-C int8 restatement (oracle/tg_oracle.c), one thread: what a scalar CPU loop over the
+    # build's own int8 layout does -- informational, not the reference's arithmetic dtypes
+    c_rate = None
+    try:
+        from oracle.c_oracle import COracle
+
+        co = COracle()
+        st8 = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+        ac8 = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)).astype(np.int8)
+        co.step_i8(st8, ac8)
+        c_n, t2 = 0, time.perf_counter()
+        while time.perf_counter() - t2 < 2.0:
+            co.step_i8(st8, ac8)
+            c_n += 1
+        c_rate = round(B * c_n / (time.perf_counter() - t2), 1)
+    except Exception as e:  # the C oracle is optional test infrastructure
+        c_rate = f"unavailable: {e}"
     return {"value": round(B * n / el, 1), "unit": "steps/s", "cores": best, "kind": "port",
+            "c_int8_port_1thread_steps_per_s": c_rate,
             "sample": f"{n} batched steps of the same workload (B={B}, S={S}; fp32 state, int64 tokens, "
                       f"torch-CPU op sequence of get_child_states + zero check) in {el:.1f} s; "
                       f"thread-count sweep (batched steps/s): " + ", ".join(f"{k}:{v:.1f}" for k, v in trials.items()),
