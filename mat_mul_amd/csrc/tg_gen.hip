@@ -142,6 +142,58 @@ __global__ __launch_bounds__(kBlock) void gen_tokens_kernel(int8_t* actions_out,
   }
 }
 
+// Change of basis on the FACTORS, in place on the token array: for game b and mode x the R vectors
+// f_r (tokens - shift) become M_x f_r.  One workgroup of three wavefronts per game -- wavefront x
+// does mode x.  The game's token block (R*3S contiguous bytes, tiled by RT actions) is staged
+// through LDS so that global reads and writes are coalesced; lane r keeps its vector f_r in
+// registers, and the matrix entries M_x[a][i] are the same for every lane: LDS broadcast reads.
+// Tokens that leave int8 wrap and raise the game's overflow flag (the target is then built from
+// the emitted, wrapped tokens).  ST = 0: runtime S (vector in scratch; correctness fallback).
+template <int ST>
+__global__ __launch_bounds__(192) void basis_tokens_kernel(int8_t* actions, uint8_t* overflow, int64_t B, int Srt,
+                                                           int R, int shift, const int8_t* basis) {
+  constexpr int SMAX = ST ? ST : TG_MAX_S;
+  constexpr int RT = 64;  // actions per tile: one per lane
+  extern __shared__ __attribute__((aligned(16))) int bt_lds[];
+  const int S = ST ? ST : Srt;
+  int* Mall = bt_lds;                                           // 3*S*S ints
+  int8_t* T = reinterpret_cast<int8_t*>(bt_lds + 3 * S * S);    // RT*3S token bytes
+  const int x = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const int8_t* Msrc = basis + b * 3 * S * S;
+    for (int c = threadIdx.x; c < 3 * S * S; c += 192) Mall[c] = Msrc[c];
+    int bad = 0;
+    for (int r0 = 0; r0 < R; r0 += RT) {
+      const int nr = min(RT, R - r0);
+      int8_t* blk = actions + (b * R + r0) * 3 * S;  // nr*3S contiguous bytes
+      const int nbytes = nr * 3 * S;
+      __syncthreads();
+      for (int o = threadIdx.x; o < nbytes; o += 192) T[o] = blk[o];
+      __syncthreads();
+      if (lane < nr) {
+        int8_t* v = T + lane * 3 * S + x * S;
+        const int* M = Mall + x * S * S;
+        int f[SMAX];
+#pragma unroll
+        for (int i = 0; i < SMAX; ++i) f[i] = (i < S) ? v[i] - shift : 0;
+        for (int a = 0; a < S; ++a) {
+          int acc = 0;
+#pragma unroll
+          for (int i = 0; i < SMAX; ++i)
+            if (i < S) acc += M[a * S + i] * f[i];
+          const int tokv = acc + shift;
+          bad |= tokv + 128;
+          v[a] = static_cast<int8_t>(tokv);
+        }
+      }
+      __syncthreads();
+      for (int o = threadIdx.x; o < nbytes; o += 192) blk[o] = T[o];
+    }
+    bad = __syncthreads_or(bad & ~255);
+    if (threadIdx.x == 0 && overflow && bad) overflow[b] = 1;
+  }
+}
+
 // One workgroup per (game, mode): L and U cells from one draw each, then P = L @ U.
 __global__ __launch_bounds__(kBlock) void sample_basis_kernel(int8_t* P, int8_t* Lo, int8_t* Uo, int64_t B, int S,
                                                               Dist D, uint64_t seed, uint64_t gid0) {
@@ -293,7 +345,7 @@ int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, 
     const int64_t wgs = (nvec + tg::kBlock * M - 1) / (tg::kBlock * M);                                   \
     hipLaunchKernelGGL((tg::gen_tokens_kernel<ST, M>), dim3(grid_for(wgs > 16384 ? 16384 : wgs)),        \
                        dim3(tg::kBlock), 0, st, actions_out, overflow, B, S, R, D, shift, seed,           \
-                       game_id_offset, basis, vec16);                                                     \
+                       game_id_offset, nullptr, vec16);                                                     \
   } while (0)
   switch (S) {
     case 4:  // 24 % of the draws are rejected: several vectors per lane, as long as the chip stays full
@@ -310,6 +362,17 @@ int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, 
     default: TG_GT(0, 1); break;
   }
 #undef TG_GT
+  if (basis) {
+    const size_t lds = 3 * static_cast<size_t>(S) * S * sizeof(int) + 64 * 3 * static_cast<size_t>(S);
+    const dim3 bgrid(grid_for(B > 16384 ? 16384 : B)), bblock(192);
+    switch (S) {
+      case 4: hipLaunchKernelGGL(tg::basis_tokens_kernel<4>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
+      case 9: hipLaunchKernelGGL(tg::basis_tokens_kernel<9>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
+      case 16: hipLaunchKernelGGL(tg::basis_tokens_kernel<16>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
+      case 25: hipLaunchKernelGGL(tg::basis_tokens_kernel<25>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
+      default: hipLaunchKernelGGL(tg::basis_tokens_kernel<0>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
+    }
+  }
   if (int rc = launched(fn)) return rc;
   return tg_gen_from_factors_i8(actions_out, target_out, overflow, B, S, R, game_stride_bytes, shift, stream);
 }

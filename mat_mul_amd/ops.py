@@ -299,10 +299,16 @@ def gen_demos(B: int, S: int, R: int, device, values=(-1, 0, 1), probs=(0.15, 0.
     return actions, target
 
 
-def sample_basis(B: int, S: int, device, values=(-1, 0, 1), probs=(0.05, 0.9, 0.05), seed: int = 0,
+def sample_basis(B: int, S: int, device, values=(-1, 0, 1), probs=None, seed: int = 0,
                  game_id_offset: int = 0, want_factors: bool = False):
-    """Three random unimodular matrices per game, P = L @ U (not in the reference)."""
+    """Three random unimodular matrices per game, P = L @ U (not in the reference).
+    ``probs`` are the off-diagonal value weights of L and U; the default keeps about 0.4 non-zero
+    off-diagonal entries per row (p = min(0.15, 0.4/S) each for -1 and +1), dense enough to mix
+    the basis and sparse enough that transformed int8 targets rarely overflow."""
     dev = torch.device(device)
+    if probs is None:
+        p = min(0.15, 0.4 / S)
+        probs = (p, 1.0 - 2.0 * p, p)
     thr, vals, thr_p, val_p, nv = _dist(values, probs, "sample_basis")
     P = torch.empty((B, 3, S, S), dtype=torch.int8, device=dev)
     L = torch.empty_like(P) if want_factors else None
