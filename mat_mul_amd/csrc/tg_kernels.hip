@@ -716,7 +716,9 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
   }
 #undef TG_ROWS
   if (al && flim >= 1 && !force_i32) {
-    if (a.S == 9) TG_PACKED(9, 64);
+    // S=9: a game is only 46 chunks, so a wavefront takes FOUR games (teams of 16 lanes, 9 active, 6
+    // chunks per lane): measured 0.48 of the HBM peak at 2^19 games against 0.43 (TS=32) and 0.29 (TS=64)
+    if (a.S == 9) TG_PACKED(9, 16);
     if (a.S == 16) TG_PACKED(16, 64);
     if (a.S == 25) TG_PACKED(25, 256);
   }
