@@ -17,46 +17,61 @@ namespace tg {
 template <typename OutT>
 __global__ __launch_bounds__(kBlock) void emit_frames_kernel(const int8_t* ring, OutT* out, float* scalars,
                                                              int64_t B, int N, int T, int head_slot, float t_step,
-                                                             int64_t frame_stride, int64_t game_stride, int vec16) {
+                                                             int64_t frame_stride, int64_t game_stride, int vec) {
+  // The output (B,T,N) is one flat, 16-byte-aligned array: one thread per 16 OUTPUT bytes (PER = 4
+  // floats or 8 halves) of that flat array, so a wavefront always stores one contiguous KiB whatever
+  // N is.  A group whose PER source bytes lie in one frame and are PER-aligned is one dword/dwordx2
+  // load (vec); otherwise (odd N: groups straddle frames) the source bytes are gathered one by one.
+  constexpr int PER = 16 / sizeof(OutT);
   const int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int64_t nthr = static_cast<int64_t>(gridDim.x) * kBlock;
   if (scalars)
     for (int64_t b = tid; b < B; b += nthr) scalars[b] = t_step;
-  const int nchunk = (N + 15) >> 4;
-  const int64_t total = B * T * nchunk;
-  for (int64_t idx = tid; idx < total; idx += nthr) {
-    const int64_t bf = idx / nchunk;  // b*T + f
-    const int c = static_cast<int>(idx - bf * nchunk);
-    const int64_t b = bf / T;
-    const int f = static_cast<int>(bf - b * T);
-    int slot = head_slot - f;
-    if (slot < 0) slot += T;
-    const int8_t* src = ring + b * game_stride + slot * frame_stride + 16 * c;
-    OutT* dst = out + bf * N + 16 * c;
-    const int nvalid = min(16, N - 16 * c);
-    if (vec16 && nvalid == 16) {
-      const uint4 q = *reinterpret_cast<const uint4*>(src);
-      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-      OutT v[16];
+  const int64_t total = B * T * N;  // output elements
+  for (int64_t q = tid * PER; q < total; q += nthr * PER) {
+    const int64_t bf = q / N;  // b*T + f of the first element
+    const int e0 = static_cast<int>(q - bf * N);
+    auto frame_ptr = [&](int64_t bfi) {
+      const int64_t b = bfi / T;
+      const int f = static_cast<int>(bfi - b * T);
+      int slot = head_slot - f;
+      if (slot < 0) slot += T;
+      return ring + b * game_stride + slot * frame_stride;
+    };
+    const int8_t* src = frame_ptr(bf);
+    OutT v[PER];
+    if (vec && e0 + PER <= N) {
+      // the group lies inside one frame; frames are 4-byte aligned (vec), the group need not be:
+      // aligned dwords + v_alignbyte.  The extra dword is only touched when the group is misaligned,
+      // and then it still starts below 4*ceil(N/4) <= frame stride.
+      const uint32_t* a = reinterpret_cast<const uint32_t*>(src + (e0 & ~3));
+      const uint32_t sh = static_cast<uint32_t>(e0 & 3);
+      uint32_t w[PER / 4];
+      uint32_t lo = a[0];
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[4 * d + t] = static_cast<OutT>(static_cast<float>(sbyte(w[d], t)));
-      // N*sizeof(OutT) need not be a multiple of 16: vector stores only when the destination is aligned
-      if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-        constexpr int PER = 16 / sizeof(OutT);
-#pragma unroll
-        for (int k = 0; k < 16 / PER; ++k) {
-          uint4 o;
-          __builtin_memcpy(&o, &v[k * PER], 16);
-          reinterpret_cast<uint4*>(dst)[k] = o;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) dst[t] = v[t];
+      for (int d = 0; d < PER / 4; ++d) {
+        const bool need_hi = sh != 0 || d + 1 < PER / 4;
+        const uint32_t hi = need_hi ? a[d + 1] : 0u;
+        w[d] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        lo = hi;
       }
+#pragma unroll
+      for (int t = 0; t < PER; ++t) v[t] = static_cast<OutT>(static_cast<float>(sbyte(w[t >> 2], t & 3)));
     } else {
-      for (int t = 0; t < nvalid; ++t) dst[t] = static_cast<OutT>(static_cast<float>(src[t]));
+      const int8_t* nxt = (e0 + PER > N && bf + 1 < B * T) ? frame_ptr(bf + 1) : src;
+#pragma unroll
+      for (int t = 0; t < PER; ++t) {
+        const int e = e0 + t;
+        const int8_t x = (q + t < total) ? (e < N ? src[e] : nxt[e - N]) : static_cast<int8_t>(0);
+        v[t] = static_cast<OutT>(static_cast<float>(x));
+      }
+    }
+    if (q + PER <= total) {
+      uint4 o;
+      __builtin_memcpy(&o, v, 16);
+      *reinterpret_cast<uint4*>(out + q) = o;
+    } else {
+      for (int t = 0; q + t < total; ++t) out[q + t] = v[t];
     }
   }
 }
@@ -116,9 +131,17 @@ __global__ __launch_bounds__(kBlock) void hash_kernel(const int8_t* state, uint6
 // of the pivot row (readlane via shuffle) and a cross-multiplied update (no modular inverse):
 // row_r <- row_r * piv_c - row_p * row_r[c]  (mod p).  Run for two primes, ranks maxed.
 // ---------------------------------------------------------------------------------------------
+// a*b mod P for P = 2^31 - C (C = 1 or 19), a, b < P: 2^31 == C (mod P), so the 62-bit product folds
+// twice by shift-multiply-add instead of a 64-bit division.
 template <uint32_t P>
 __device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) {
-  return static_cast<uint32_t>((static_cast<uint64_t>(a) * b) % P);
+  constexpr uint64_t C = (1ull << 31) - P;
+  uint64_t x = static_cast<uint64_t>(a) * b;           // < 2^62
+  x = (x & 0x7FFFFFFFull) + (x >> 31) * C;             // < 2^31 + 2^31*C
+  x = (x & 0x7FFFFFFFull) + (x >> 31) * C;             // < 2^31 + C*C
+  uint32_t r = static_cast<uint32_t>(x);
+  if (r >= P) r -= P;
+  return r;
 }
 
 template <int ST, uint32_t P>
@@ -141,8 +164,9 @@ __device__ __forceinline__ int slice_rank(const int8_t* m, int S, int lane) {
         const uint32_t pc = __shfl(row[c], pr);
         const uint32_t mine = row[c];
         const bool upd = !used && lane != pr && mine != 0;
+        // columns < c of every unused row were zeroed by earlier pivots, and column c becomes zero
 #pragma unroll
-        for (int k = 0; k < SMAX; ++k) {
+        for (int k = c + 1; k < SMAX; ++k) {
           if (k < S) {
             const uint32_t pk = __shfl(row[k], pr);
             if (upd) {
@@ -151,6 +175,7 @@ __device__ __forceinline__ int slice_rank(const int8_t* m, int S, int lane) {
             }
           }
         }
+        if (upd) row[c] = 0;
         if (lane == pr) used = true;
         ++rank;
       }
@@ -217,10 +242,13 @@ int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_is_f16
   if (B == 0) return TG_OK;
   if (!ring || !out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
   const int N = S * S * S;
-  const int vec16 = (reinterpret_cast<uintptr_t>(ring) & 15) == 0 && frame_stride_bytes % 16 == 0 &&
-                    game_stride_bytes % 16 == 0;
-  const int64_t work = B * T * ((N + 15) / 16);
-  const dim3 grid(grid_for((work + tg::kBlock - 1) / tg::kBlock, 16384)), block(tg::kBlock);
+  if (reinterpret_cast<uintptr_t>(out) & 15) return tg_internal_fail(TG_ERR_INVALID, "%s: out must be 16-byte aligned", fn);
+  // dword loads need 4-byte aligned frames
+  const int per = out_is_f16 ? 8 : 4;
+  const int vec16 = (reinterpret_cast<uintptr_t>(ring) % 4) == 0 && frame_stride_bytes % 4 == 0 &&
+                    game_stride_bytes % 4 == 0;
+  const int64_t work = (B * T * N + per - 1) / per;
+  const dim3 grid(grid_for((work + tg::kBlock - 1) / tg::kBlock, 32768)), block(tg::kBlock);
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();
   if (out_is_f16)

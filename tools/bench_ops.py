@@ -104,6 +104,23 @@ def main():
         start = target[0].contiguous()
         t = timeit(lambda: ops.reset_broadcast(state, start), iters=50)
         emit("reset_broadcast", S, B, t, nbytes=B * N, units=B)
+        # next rows: model input, hash, rank
+        T = 4
+        ring = ops.alloc_ring(B, S, T, DEV)
+        ring[:, 0].copy_(target)
+        x32 = torch.empty((B, T, S, S, S), dtype=torch.float32, device=DEV)
+        sc = torch.empty((B, 1), dtype=torch.float32, device=DEV)
+        t = timeit(lambda: ops.emit_frames(ring, 0, 1.0, torch.float32, out=x32, scalars=sc))
+        emit("emit_frames f32 T=4", S, B, t, nbytes=B * T * N * 5, units=B)
+        x16 = torch.empty((B, T, S, S, S), dtype=torch.float16, device=DEV)
+        t = timeit(lambda: ops.emit_frames(ring, 0, 1.0, torch.float16, out=x16, scalars=sc))
+        emit("emit_frames f16 T=4", S, B, t, nbytes=B * T * N * 3, units=B)
+        del x32, x16, ring
+        t = timeit(lambda: ops.state_hash(target), iters=50)
+        emit("state_hash", S, B, t, nbytes=B * (N + 8), units=B)
+        Br = min(B, 16384)
+        t = timeit(lambda: ops.slice_rank(target[:Br]))
+        emit("slice_rank", S, Br, t, nbytes=Br * (N + 4), units=Br, macs=Br * 2 * S * S * S * S)
         # basis
         Bb = min(B, 8192)
         P = ops.sample_basis(Bb, S, DEV, seed=3)
