@@ -107,3 +107,19 @@ def uvw_to_demo(uu: torch.Tensor, vv: torch.Tensor, ww: torch.Tensor, device="cu
     tokens = ops.as_tokens(torch.cat((uu, vv, ww), dim=1) + shift, device)
     S = uu.shape[1]
     return ops.gen_from_factors(tokens.unsqueeze(0), S, shift=shift)[0], tokens
+
+
+def take_action(state_batch: torch.Tensor, tokens: torch.Tensor, n_samples: int, shift: int = 2):
+    """reference training.py:249-268 (SyntheticDemoTrainingApp._take_action, minus the model call that
+    produces ``tokens``): one batched env step with history shift, the per-game non-zero count
+    (``rank_ubs``, :266) grouped by ``n_samples``, and the best sample per group (:267).
+    state_batch int8 (B,T,S,S,S); tokens (B,3S) with the reference's ``- 2`` shift (:253).
+    Returns (new_state_batch (B,T,S,S,S), rank_ubs int32 (B/n_samples, n_samples), best (values, indices))."""
+    state = _as_state(state_batch)
+    B, T, S = state.shape[0], state.shape[1], state.shape[2]
+    head = state[:, 0].contiguous()
+    new_head, _ = ops.step(head, ops.as_tokens(tokens, state.device), shift=shift)
+    new_state = torch.cat((new_head.unsqueeze(1), state), dim=1)[:, :-1]   # :256-258
+    _, nnz = ops.done(new_head, want_nnz=True)
+    rank_ubs = nnz.view(-1, n_samples)
+    return new_state, rank_ubs, torch.min(rank_ubs, -1)

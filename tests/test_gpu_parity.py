@@ -627,3 +627,20 @@ def test_randomized_differential():
         assert np.array_equal(host(ops.state_hash(t)).view(np.uint64), O.state_hash(st))
         n_cases += 1
     assert n_cases == 120
+
+
+def test_take_action_batched_greedy_step():
+    """functional.take_action == the arithmetic of training.py:249-268 restated with the oracle."""
+    rng = np.random.default_rng(12)
+    S, T, n, groups = 4, 3, 4, 5
+    B = n * groups
+    st = rng.integers(-1, 2, size=(B, T, S, S, S)).astype(np.int8)
+    tok = rng.integers(1, 4, size=(B, 3 * S)).astype(np.int8)          # tokens {1,2,3}, shift 2
+    new_state, rank_ubs, best = F.take_action(dev(st), dev(tok), n_samples=n)
+    head = st[:, 0].astype(np.int64) - O.action_to_tensor(tok, shift=2)
+    want_state = np.concatenate([head[:, None], st[:, :-1].astype(np.int64)], axis=1)
+    want_ubs = (head != 0).reshape(B, -1).sum(1).reshape(groups, n)
+    assert np.array_equal(host(new_state), want_state)
+    assert np.array_equal(host(rank_ubs), want_ubs)
+    assert np.array_equal(host(best.values), want_ubs.min(1))
+    assert np.array_equal(want_ubs[np.arange(groups), host(best.indices)], want_ubs.min(1))
