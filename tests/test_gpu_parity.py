@@ -644,3 +644,90 @@ def test_take_action_batched_greedy_step():
     assert np.array_equal(host(rank_ubs), want_ubs)
     assert np.array_equal(host(best.values), want_ubs.min(1))
     assert np.array_equal(want_ubs[np.arange(groups), host(best.indices)], want_ubs.min(1))
+
+
+def test_no_out_of_bounds_writes():
+    """Guard bytes before/after every output buffer and in the padding between games must survive every
+    entry point, for aligned, padded and packed layouts."""
+    GUARD, CANARY = 256, 0x5A
+    rng = np.random.default_rng(99)
+
+    def guarded_states(B, S, stride):
+        n = S ** 3
+        buf = torch.full((GUARD + B * stride + GUARD,), CANARY, dtype=torch.uint8, device=DEV).view(torch.int8)
+        view = buf[GUARD:GUARD + B * stride].view(B, stride)[:, :n].unflatten(1, (S, S, S))
+        return buf, view
+
+    def check(buf, B, S, stride, what):
+        raw = host(buf.view(torch.uint8))
+        n = S ** 3
+        assert (raw[:GUARD] == CANARY).all() and (raw[GUARD + B * stride:] == CANARY).all(), what
+        body = raw[GUARD:GUARD + B * stride].reshape(B, stride)
+        assert (body[:, n:] == CANARY).all(), what + " (padding between games)"
+
+    def guarded(shape, dtype):
+        numel = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        buf = torch.full((GUARD + numel + GUARD,), CANARY, dtype=torch.uint8, device=DEV)
+        return buf, buf[GUARD:GUARD + numel].view(dtype).view(shape)
+
+    def check_flat(buf, what):
+        raw = host(buf)
+        assert (raw[:GUARD] == CANARY).all() and (raw[-GUARD:] == CANARY).all(), what
+
+    for S in (4, 9, 16, 25, 6):
+        n = S ** 3
+        for stride in {n, -(-n // 16) * 16, -(-n // 16) * 16 + 32}:
+            B, K = 7, 5
+            st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+            ac = dev(rng.integers(0, 3, size=(B, K, 3 * S)).astype(np.int8))
+            sbuf, src = guarded_states(B, S, stride)
+            src.copy_(dev(st))
+            for name in ("step", "step_many", "gen_from_factors", "reset_matmul", "reset_broadcast", "change_basis"):
+                obuf, out = guarded_states(B, S, stride)
+                dbuf, done = guarded((B,), torch.uint8)
+                if name == "step":
+                    ops.step(src, ac[:, 0].contiguous(), out=out, done=done)
+                elif name == "step_many":
+                    d2buf, ds = guarded((B,), torch.int32)
+                    ops.step_many(src, ac, out=out, done_step=ds)
+                    check_flat(d2buf, name)
+                elif name == "gen_from_factors":
+                    ops.gen_from_factors(ac, S, out=out)
+                elif name == "reset_matmul":
+                    if int(np.sqrt(S)) ** 2 != S:
+                        continue
+                    ops.reset_matmul(out, int(np.sqrt(S)))
+                elif name == "reset_broadcast":
+                    ops.reset_broadcast(out, dev(st[0]))
+                else:
+                    eye = torch.eye(S, dtype=torch.int32, device=DEV).expand(B, 3, S, S).contiguous()
+                    ops.change_basis(src, eye, out=out)
+                torch.cuda.synchronize()
+                check(obuf, B, S, stride, f"{name} S={S} stride={stride}")
+                check_flat(dbuf, name)
+            check(sbuf, B, S, stride, f"inputs S={S} stride={stride}")
+            # expand: children buffer (B*k games) + flags
+            k = 3
+            cbuf, kids = guarded_states(B * k, S, stride)
+            fbuf, flags = guarded((3, B, k), torch.uint8)
+            ops.expand(src, ac[:, :k].contiguous(), out=kids.unflatten(0, (B, k)), done=flags[0], changed=flags[1],
+                       overflow=flags[2])
+            torch.cuda.synchronize()
+            check(cbuf, B * k, S, stride, f"expand S={S} stride={stride}")
+            check_flat(fbuf, "expand flags")
+        # generator, hash, rank, emit_frames
+        tbuf, tok = guarded((5, 4, 3 * S), torch.int8)
+        gbuf, tgt = guarded_states(5, S, -(-n // 16) * 16)
+        ops.gen_demos(5, S, 4, DEV, seed=1, target=tgt, actions=tok)
+        torch.cuda.synchronize()
+        check_flat(tbuf, "gen_demos tokens")
+        check(gbuf, 5, S, -(-n // 16) * 16, "gen_demos target")
+        ring = ops.alloc_ring(3, S, 2, DEV)
+        for dt in (torch.float32, torch.float16):
+            xbuf, x = guarded((3, 2, S, S, S), dt)
+            scbuf, sc = guarded((3, 1), torch.float32)
+            if x.data_ptr() % 16 == 0:
+                ops.emit_frames(ring, 1, 2.0, dt, out=x, scalars=sc)
+                torch.cuda.synchronize()
+                check_flat(xbuf, "emit_frames")
+                check_flat(scbuf, "emit_frames scalars")
