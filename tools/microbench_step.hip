@@ -249,5 +249,47 @@ int main(int argc, char** argv) {
     printf("product tg_step_i8 (overflow %s)  graph %.3f us/launch (%.0f GB/s alg)\n", rep ? "tracked" : "NULL",
            ms * 1e3 / N, B * 141.0 / (ms * 1e-3 / N) / 1e9);
   }
+  // ---- split the batch into P independent chains inside ONE graph (fork/join by events) ----
+  for (int P : {1, 2, 4, 8}) {
+    CK(hipMemcpy(st, hs.data(), hs.size(), hipMemcpyHostToDevice));
+    std::vector<hipStream_t> ss(P);
+    std::vector<hipEvent_t> ev(P);
+    for (int p = 0; p < P; ++p) {
+      CK(hipStreamCreate(&ss[p]));
+      CK(hipEventCreateWithFlags(&ev[p], hipEventDisableTiming));
+    }
+    hipEvent_t fork;
+    CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    const int Bp = B / P;
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    CK(hipEventRecord(fork, s));
+    for (int p = 0; p < P; ++p) CK(hipStreamWaitEvent(ss[p], fork, 0));
+    for (int i = 0; i < N; ++i)
+      for (int p = 0; p < P; ++p)
+        if (tg_step_i8((const int8_t*)st + (size_t)p * Bp * 64, (int8_t*)st + (size_t)p * Bp * 64,
+                       (const int8_t*)tok + (size_t)p * Bp * 12, done + (size_t)p * Bp, nullptr, Bp, 4, 64, 1, ss[p]))
+          return 1;
+    for (int p = 0; p < P; ++p) {
+      CK(hipEventRecord(ev[p], ss[p]));
+      CK(hipStreamWaitEvent(s, ev[p], 0));
+    }
+    CK(hipStreamEndCapture(s, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, s));
+    CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, s));
+    CK(hipGraphLaunch(ge, s));
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("product, %d independent chains of %d games: %.3f us per full-batch step (%.0f GB/s alg)\n", P, Bp,
+           ms * 1e3 / N, B * 141.0 / (ms * 1e-3 / N) / 1e9);
+  }
   return 0;
 }
