@@ -677,7 +677,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
   // packed int16 path: exact while nact * f^3 <= 32000 for every |factor| <= f (checked on device)
   int flim = 0;
   if constexpr (MODE == MANY) {
-    flim = 5;  // lattice form (tg_packed.h): every |u_i v_j w_l| <= 125 fits one int8 step
+    flim = 127;  // lattice form (tg_packed.h): u*v and 256*w must be representable in int16
   } else {
     const int64_t n = (MODE == GENF) ? a.nact : 1;
     while (flim < 31 && static_cast<int64_t>(flim + 1) * (flim + 1) * (flim + 1) * n <= 32000) ++flim;

@@ -26,7 +26,9 @@
 // != 0x80) for good, because every later increment is a multiple of 256.  So the range check is
 // ONE test at the end; a game that fails it is recomputed by the exact byte-wise form before
 // anything is stored.  While on the lattice, "state is zero" <=> OR of all x has zero high bytes.
-// The lattice needs |u_i v_j w_l| <= 127 per action, i.e. |factor| <= 5.
+// v_pk_mad_i16 ... clamp forms a*b + c exactly and then saturates, so a single step may move an
+// entry by more than 127 as long as it lands in range (-128 + 200 = 72 is exact); the lattice
+// only needs representable operands: |u_i v_j| <= 32767 and |256 w_l| <= 32767, i.e. |factor| <= 127.
 constexpr uint32_t kLatticeZero = 0x00800080u;
 
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }

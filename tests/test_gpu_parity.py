@@ -480,6 +480,33 @@ def test_slice_rank_golden_and_oracle(golden):
     assert host(env.rank_reward()).tolist() == [-8, -8, -8]           # <2,2,2>: four slices of rank 2
 
 
+@pytest.mark.parametrize("S,B,K", [(9, 12, 4), (16, 8, 5), (25, 4, 3), (9, 6, 2)])
+def test_step_many_moderate_factors_stay_on_fast_path(S, B, K):
+    """Factors up to +-11 (single updates of up to 1331 on sparse vectors) with states that stay in int8:
+    the saturating lattice form must be exact, and must not need the fallback."""
+    rng = np.random.default_rng(S + K)
+    ac = np.ones((B, K, 3 * S), np.int8)                                   # factor 0 everywhere (shift 1)
+    for b in range(B):
+        for k in range(K):
+            for part, lo, hi in ((0, -11, 12), (1, -11, 12), (2, -1, 2)):      # one non-zero u_i, v_j; w in {-1,0,1}
+                if part < 2:
+                    ac[b, k, part * S + rng.integers(S)] = 1 + rng.integers(lo, hi)
+                else:
+                    ac[b, k, 2 * S:] = 1 + rng.integers(lo, hi, size=S)
+    st = rng.integers(-3, 4, size=(B, S, S, S)).astype(np.int8)
+    want, want_ds, want_ovf = O.step_many_i8(st, ac)
+    # keep only games whose path stays in range at every step (the others legitimately fall back)
+    keep = want_ovf == 0
+    assert keep.sum() >= 1
+    st, ac, want, want_ds = st[keep], ac[keep], want[keep], want_ds[keep]
+    before = ops.debug_fallbacks(DEV)
+    ovf = torch.zeros(len(st), dtype=torch.uint8, device=DEV)
+    out, ds = ops.step_many(padded(st), dev(ac), overflow=ovf)
+    assert np.array_equal(host(out), want) and np.array_equal(host(ds), want_ds) and not host(ovf).any()
+    assert np.abs(ac.astype(int) - 1).max() > 5
+    assert ops.debug_fallbacks(DEV) == before
+
+
 def test_default_vocabulary_never_falls_back():
     """The packed/rows kernels silently fall back to a 10-50x slower exact form for out-of-range
     factors or int8 overflow; ordinary inputs ({-1,0,1} and {-2..2} factors, no overflow) must not."""
