@@ -474,37 +474,101 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
         if (a.overflow && any_ovf) (a.overflow + g0)[lg] = 1;
       }
     } else {
-      int acc[16];
-      unpack16(pk, acc);
-      int done_step = -1;
-      int t0 = tok[0], t1 = tok[1], t2 = tok[2];
-      for (int k = 0; k < a.nact; ++k) {
-        const int cur[3] = {t0, t1, t2};
-        if (k + 1 < a.nact) {  // prefetch the next action's tokens
-          t0 = tok[3 * (k + 1)];
-          t1 = tok[3 * (k + 1) + 1];
-          t2 = tok[3 * (k + 1) + 2];
+      // exact 32-bit form: GENF always; MANY for teams the lattice form below hands over
+      auto many_i32 = [&]() {
+        int acc[16];
+        unpack16(pk, acc);
+        int done_step = -1;
+        int t0 = tok[0], t1 = tok[1], t2 = tok[2];
+        for (int k = 0; k < a.nact; ++k) {
+          const int cur[3] = {t0, t1, t2};
+          if (k + 1 < a.nact) {  // prefetch the next action's tokens
+            t0 = tok[3 * (k + 1)];
+            t1 = tok[3 * (k + 1) + 1];
+            t2 = tok[3 * (k + 1) + 2];
+          }
+          const S4Factors f = s4_factors<MODE != GENF>(cur, q, a.shift);
+          int chg = 0;
+          s4_rank1(acc, f, chg);
+          if constexpr (MODE == MANY) {
+            uint32_t nz = 0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+              nz |= static_cast<uint32_t>(acc[t]);
+              ovf |= acc[t] + 128;
+            }
+            if (!team_any<4>((nz & 255) != 0) && done_step < 0) done_step = k;
+          }
         }
-        const S4Factors f = s4_factors<MODE != GENF>(cur, q, a.shift);
-        int chg = 0;
-        s4_rank1(acc, f, chg);
-        if constexpr (MODE == MANY) {
+        uint32_t nz = 0;
+        const uint4 o = pack16(acc, nz, ovf);
+        if (live) *reinterpret_cast<uint4*>(out_blk + out_off) = o;
+        const bool any_ovf = team_any<4>((ovf & ~255) != 0);
+        if (q == 0 && live) {
+          if constexpr (MODE == MANY) (a.done_step + g0)[lg] = done_step;
+          if (a.overflow && any_ovf) (a.overflow + g0)[lg] = 1;
+        }
+      };
+      if constexpr (MODE == GENF) {
+        many_i32();
+      } else {
+        // step_many on the saturating int16 lattice (tg_packed.h): x = 256 n + 128 per half, weights
+        // 256 w, v_pk_mad_i16 clamp; the zero test is an OR, the int8 range check one test at the end.
+        // Operands must be representable (every factor in [-128,127]); teams that are not, or that
+        // leave the lattice (an int8 overflow), are redone by many_i32 from the untouched input.
+        uint32_t A[8];
+        unpack_pairs(pk, A);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) A[p] = pk_add_u16(pk_lshl8_b16(A[p]), kLatticeZero);
+        const uint32_t shp = __builtin_amdgcn_perm(static_cast<uint32_t>(a.shift), static_cast<uint32_t>(a.shift), 0x05040100u);
+        uint32_t rng1 = 0, rng2 = 0;  // range accumulators: (x + 128) must stay below 256
+        int done_step = -1;
+        int t0 = tok[0], t1 = tok[1], t2 = tok[2];
+        for (int k = 0; k < a.nact; ++k) {
+          const uint32_t du = t0, dv = t1, dw = t2;
+          if (k + 1 < a.nact) {
+            t0 = tok[3 * (k + 1)];
+            t1 = tok[3 * (k + 1) + 1];
+            t2 = tok[3 * (k + 1) + 2];
+          }
+          const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(du), 8 * q, 8);  // -(u_i)
+          rng1 |= static_cast<uint32_t>(ui + 128);
+          const uint32_t yv = dv << 8, yw = dw << 8;
+          const uint32_t vA = pk_sub_i16(__builtin_amdgcn_perm(dv, yv, 0x0A050804u), shp);  // (v0, v1)
+          const uint32_t vB = pk_sub_i16(__builtin_amdgcn_perm(dv, yv, 0x0B070906u), shp);  // (v2, v3)
+          uint32_t wA = pk_sub_i16(__builtin_amdgcn_perm(dw, yw, 0x0A050804u), shp);        // (w0, w1)
+          uint32_t wB = pk_sub_i16(__builtin_amdgcn_perm(dw, yw, 0x0B070906u), shp);        // (w2, w3)
+          rng2 |= pk_add_u16(vA, kLatticeZero) | pk_add_u16(vB, kLatticeZero) | pk_add_u16(wA, kLatticeZero) |
+                  pk_add_u16(wB, kLatticeZero);
+          const uint32_t uip = __builtin_amdgcn_perm(static_cast<uint32_t>(ui), static_cast<uint32_t>(ui), 0x05040100u);
+          const uint32_t uvA = pk_mul_lo_u16(vA, uip), uvB = pk_mul_lo_u16(vB, uip);  // (-u v0, -u v1), (-u v2, -u v3)
+          wA = pk_lshl8_b16(wA);
+          wB = pk_lshl8_b16(wB);
+          const uint32_t pr[4] = {__builtin_amdgcn_perm(uvA, uvA, 0x01000100u), __builtin_amdgcn_perm(uvA, uvA, 0x03020302u),
+                                  __builtin_amdgcn_perm(uvB, uvB, 0x01000100u), __builtin_amdgcn_perm(uvB, uvB, 0x03020302u)};
           uint32_t nz = 0;
 #pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            nz |= static_cast<uint32_t>(acc[t]);
-            ovf |= acc[t] + 128;
+          for (int j = 0; j < 4; ++j) {
+            A[2 * j] = pk_mad_i16_sat(pr[j], wA, A[2 * j]);
+            A[2 * j + 1] = pk_mad_i16_sat(pr[j], wB, A[2 * j + 1]);
+            nz |= A[2 * j] | A[2 * j + 1];
           }
-          if (!team_any<4>((nz & 255) != 0) && done_step < 0) done_step = k;
+          if (!team_any<4>((nz & 0xFF00FF00u) != 0) && done_step < 0) done_step = k;
         }
-      }
-      uint32_t nz = 0;
-      pk = pack16(acc, nz, ovf);
-      if (live) *reinterpret_cast<uint4*>(out_blk + out_off) = pk;
-      const bool any_ovf = team_any<4>((ovf & ~255) != 0);
-      if (q == 0 && live) {
-        if constexpr (MODE == MANY) (a.done_step + g0)[lg] = done_step;
-        if (a.overflow && any_ovf) (a.overflow + g0)[lg] = 1;
+        uint32_t off = (rng1 & ~0xFFu) | (rng2 & 0xFF00FF00u);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) off |= (A[p] ^ kLatticeZero) & 0x00FF00FFu;
+        const bool bad = team_any<4>(off != 0);
+        if (!bad) {
+          uint32_t w[4];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) w[d] = __builtin_amdgcn_perm(A[2 * d + 1], A[2 * d], 0x07050301u);
+          if (live) *reinterpret_cast<uint4*>(out_blk + out_off) = uint4{w[0], w[1], w[2], w[3]};
+          if (q == 0 && live) (a.done_step + g0)[lg] = done_step;
+        } else {
+          if (threadIdx.x == (threadIdx.x & ~3)) atomicAdd(&g_fallback_workgroups, 1ull);  // one per team
+          many_i32();
+        }
       }
     }
   } else {  // EXPAND: child (g, k) lives at out + (g*nact + k) * out_stride

@@ -115,6 +115,16 @@ __device__ __forceinline__ uint32_t pk_lshl8_b16(uint32_t a) {
   asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(d) : "v"(0x00080008u), "v"(a));
   return d;
 }
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t pk_mul_lo_u16(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
   uint32_t d;
   asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
