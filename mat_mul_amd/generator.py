@@ -34,6 +34,16 @@ class SyntheticDemos:
             n_demos, dim_3d, max_actions, self.device, values=values, probs=probs, shift=shift,
             seed=seed, game_id_offset=game_id_offset, basis=basis, overflow=self.overflow)
 
+    @classmethod
+    def sharded(cls, max_actions: int, n_demos_global: int, dim_t: int, dim_3d: int, rank: int, world_size: int,
+                device="cuda", **kw):
+        """The demos [lo, hi) of an ``n_demos_global`` dataset owned by ``rank`` (contiguous range; the
+        generator is keyed by global demo id, so the shards concatenate to the single-rank dataset)."""
+        from .sharding import shard_range
+
+        lo, hi = shard_range(n_demos_global, rank, world_size)
+        return cls(max_actions, hi - lo, dim_t, dim_3d, device=device, game_id_offset=lo, **kw)
+
     def __len__(self) -> int:
         return self.n_demos * self.max_actions
 

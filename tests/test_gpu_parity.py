@@ -386,7 +386,8 @@ def test_sharded_env_equals_single_env():
     parts = []
     for rank in range(3):
         lo, hi = mat_mul_amd.shard_range(B, rank, 3)
-        sd = SyntheticDemos(R, hi - lo, 1, S, DEV, seed=4, game_id_offset=lo)
+        sd = SyntheticDemos.sharded(R, B, 1, S, rank, 3, DEV, seed=4)
+        assert sd.game_id_offset == lo and sd.n_demos == hi - lo
         assert torch.equal(sd.action_seq, demos.action_seq[lo:hi])
         e = TensorGameEnv.sharded(B, S, rank, 3, DEV)
         assert e.game_id_offset == lo and e.B == hi - lo
