@@ -13,11 +13,18 @@
 // int16 accumulation is exact under the same condition as tg_packed.h (nact * f^3 <= 32000),
 // decided by the same prescan; larger factors run the exact byte-wise form.
 
+//
+// SPARSITY.  The rows are dealt so that one wavefront "slot" holds the rows of IPS = 64/S whole
+// slices i (S = 25: two slices, 50 lanes).  u_i is then the same for all rows of a slice, and with
+// the reference's factor distribution (P(0) = 0.7, datasets.py:31) every u_i of a slot is zero half
+// of the time: a wave-uniform __ballot skips that slot's MACs for the action entirely.
 template <int S, int TS>
 struct RGeo {
   static constexpr int N = S * S * S;
   static constexpr int NROW = S * S;
-  static constexpr int NR = (NROW + TS - 1) / TS;  // rows per lane
+  static constexpr int NW = TS / 64;                          // wavefronts per team
+  static constexpr int IPS = 64 / S;                          // slices per wavefront slot
+  static constexpr int NR = (S + IPS * NW - 1) / (IPS * NW);  // slots (= rows) per lane
   static constexpr int NP = (S + 1) / 2;           // int16 pairs per row
   static constexpr int GPB = kBlock / TS;
   static constexpr int NCHUNK = (N + 15) / 16;
@@ -75,17 +82,18 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
     return;
   }
 
-  // ---- lane geometry: rows r = lt + TS*n ----------------------------------------------------------
-  int uoff[G::NR], voff[G::NR];  // byte offsets of u_i and v_j inside an action's table
+  // ---- lane geometry: slot n of wavefront wv holds slices i = (n*NW + wv)*IPS + [0, IPS) ---------
+  const int wv = lt >> 6, ln = lt & 63;
+  const int li = ln / S, lj = ln - li * S;  // lane -> (slice within the slot, row j)
+  int uoff[G::NR], voff[G::NR], rowb[G::NR];  // byte offsets of u_i, v_j in an action's table; row start in `st`
   bool rv[G::NR];
 #pragma unroll
   for (int n = 0; n < G::NR; ++n) {
-    const int r = lt + TS * n;
-    rv[n] = r < G::NROW;
-    const int i = rv[n] ? r / S : S;  // u[S] == 0: idle row slots accumulate nothing
-    const int j = rv[n] ? r - (r / S) * S : 0;
-    uoff[n] = 4 * G::NP + 2 * i;
-    voff[n] = 4 * G::NP + 2 * (S + 1 + j);
+    const int i = (n * G::NW + wv) * G::IPS + li;
+    rv[n] = li < G::IPS && i < S;
+    uoff[n] = 4 * G::NP + 2 * (rv[n] ? i : S);  // u[S] == 0: idle lanes accumulate nothing
+    voff[n] = 4 * G::NP + 2 * (S + 1 + (rv[n] ? lj : 0));
+    rowb[n] = (i * S + lj) * S;
   }
 
   // ---- state: coalesced 16-byte chunks -> LDS -> rows as int16 pairs -----------------------------
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
 #pragma unroll
     for (int n = 0; n < G::NR; ++n) {
       if (rv[n]) {
-        const int8_t* row = reinterpret_cast<const int8_t*>(st) + (lt + TS * n) * S;
+        const int8_t* row = reinterpret_cast<const int8_t*>(st) + rowb[n];
 #pragma unroll
         for (int p = 0; p < G::NP; ++p) {
           const int lo = row[2 * p] * 256 + 128;
@@ -178,6 +186,13 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
 
   uint32_t ovf = 0;
   int done_step = -1;
+  uint32_t nzs[G::NR];
+#pragma unroll
+  for (int n = 0; n < G::NR; ++n) {
+    nzs[n] = 0;
+#pragma unroll
+    for (int p = 0; p < G::NP; ++p) nzs[n] |= acc[n][p];
+  }
   if constexpr (MODE == MANY && TS == 256) {
     for (int k = tid; k < a.nact; k += kBlock) flags[k] = 0;
   }
@@ -189,22 +204,30 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
       uint32_t wp[G::NP];
 #pragma unroll
       for (int p = 0; p < G::NP; ++p) wp[p] = reinterpret_cast<const uint32_t*>(T)[p];
+      // every LDS read of the action is issued up front (one latency); only arithmetic is conditional
+      int ui[G::NR], vj[G::NR];
 #pragma unroll
       for (int n = 0; n < G::NR; ++n) {
-        const int ui = *reinterpret_cast<const short*>(T + uoff[n]);
-        const int vj = *reinterpret_cast<const short*>(T + voff[n]);
-        const int uv = mul24_pinned(ui, vj);
-        const uint32_t pr = __builtin_amdgcn_perm(static_cast<uint32_t>(uv), static_cast<uint32_t>(uv), 0x05040100u);
+        ui[n] = *reinterpret_cast<const short*>(T + uoff[n]);
+        vj[n] = *reinterpret_cast<const short*>(T + voff[n]);
+      }
 #pragma unroll
-        for (int p = 0; p < G::NP; ++p)
+      for (int n = 0; n < G::NR; ++n) {
+        if (__ballot(ui[n] != 0) == 0) continue;  // every u_i of this slot is zero: wave-uniform skip
+        const int uv = mul24_pinned(ui[n], vj[n]);
+        const uint32_t pr = __builtin_amdgcn_perm(static_cast<uint32_t>(uv), static_cast<uint32_t>(uv), 0x05040100u);
+        uint32_t o = 0;
+#pragma unroll
+        for (int p = 0; p < G::NP; ++p) {
           acc[n][p] = (MODE == MANY) ? pk_mad_i16_sat(pr, wp[p], acc[n][p]) : pk_mad_i16(pr, wp[p], acc[n][p]);
+          o |= acc[n][p];
+        }
+        nzs[n] = o;  // OR of the slot's lattice values, refreshed only when the slot changed
       }
       if constexpr (MODE == MANY) {
         uint32_t nz = 0;
 #pragma unroll
-        for (int n = 0; n < G::NR; ++n)
-#pragma unroll
-          for (int p = 0; p < G::NP; ++p) nz |= acc[n][p];
+        for (int n = 0; n < G::NR; ++n) nz |= nzs[n];
         if constexpr (TS == 256) {
           if (nz & 0xFF00FF00u) flags[a0 + k] = 1;
         } else {
@@ -247,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
 #pragma unroll
   for (int n = 0; n < G::NR; ++n) {
     if (rv[n]) {
-      uint8_t* row = st + (lt + TS * n) * S;
+      uint8_t* row = st + rowb[n];
 #pragma unroll
       for (int p = 0; p < G::NP; ++p) {
         if constexpr (MODE == MANY) {
