@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The HIP library is a git-ignored build product: compile it (hipcc cross-compiles gfx950 without
+    a GPU) when it is missing or older than its sources, so that the suite works on a fresh checkout."""
+    from mat_mul_amd import build
+
+    if build.is_stale():
+        build.build(verbose=True)
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):
