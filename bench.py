@@ -236,11 +236,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    import mat_mul_amd  # noqa: F401  (raises if libtensorgame.so is missing)
-    from mat_mul_amd import shard_range
+    from mat_mul_amd import build as tg_build, shard_range
     from mat_mul_amd.sharding import RankGroup
 
     group = RankGroup(os.environ.get("TG_BENCH_BACKEND", "nccl"), dev)  # control plane only: barrier + max of the elapsed time
+    if group.rank == 0 and tg_build.is_stale():  # normally built by __graft_entry__.build(); self-heal on a fresh tree
+        tg_build.build()
+    group.barrier()
+    from mat_mul_amd import _lib  # noqa: F401  (raises if libtensorgame.so or a symbol is missing: no CPU path)
 
     S = args.dim
     Bg = args.batch or {4: 65536, 16: 8192, 25: 4096, 9: 32768}.get(S, 4096)
