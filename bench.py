@@ -140,7 +140,10 @@ def roofline(B, S, K, event_ms):
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "kernel": "tg::s4_kernel<STEP>" if S == 4 else f"tg::packed_kernel<{S},{256 if S == 25 else 64},STEP>",
-            "bytes_per_launch": B * bytes_step(S), "avg_launch_us": round(per_launch_s * 1e6, 3)}
+            "bytes_per_launch": B * bytes_step(S), "avg_launch_us": round(per_launch_s * 1e6, 3),
+            "note": ("achieved/frac price the ALGORITHMIC bytes 2S^3+3S+1 per step; in-place steps of the S>=9 kernels "
+                     "skip the store of 16-byte chunks an action leaves unchanged, so `traffic` (PMC) can be lower")
+            if S != 4 else "achieved/frac price the algorithmic bytes 2S^3+3S+1 per step"}
 
 
 def cpu_baseline(B, S, budget_s=12.0):

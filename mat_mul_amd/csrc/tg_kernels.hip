@@ -466,6 +466,8 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
       unpack16(pk, acc);
       s4_rank1(acc, f, chg);
       pk = pack16(acc, nz, ovf);
+      // (skipping the store of untouched slices, as packed_kernel does in place, is SLOWER here: 16-byte
+      // holes inside 64-byte games turn full-line writes into partial ones -- 2.83 -> 3.05 us at cfg2)
       if (live) *reinterpret_cast<uint4*>(out_blk + out_off) = pk;
       const bool any_nz = team_any<4>(nz != 0);
       const bool any_ovf = team_any<4>((ovf & ~255) != 0);

@@ -331,10 +331,15 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
     for (int n = 0; n < G::NCH; ++n) unpack_pairs(par[n], A[n]);
     apply(F, A);
     uint32_t nz = 0;
+    const bool inplace = a.in == a.out;
 #pragma unroll
     for (int n = 0; n < G::NCH; ++n) {
       const uint4 q = pack_pairs(A[n], nz, ovf);
-      if (live && cv[n]) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * (lt + G::TSA * n), q, ctail[n]);
+      // in place, a chunk the action did not touch (u_i v_j = 0 on its rows: most chunks under the
+      // reference's factor distribution) needs no store at all
+      const bool same = inplace && q.x == par[n].x && q.y == par[n].y && q.z == par[n].z && q.w == par[n].w;
+      if (live && cv[n] && !same)
+        store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * (lt + G::TSA * n), q, ctail[n]);
     }
     bool any_nz, any_ovf;
     if constexpr (TS == 256) {
