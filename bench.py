@@ -139,7 +139,8 @@ def roofline(B, S, K, event_ms):
     traffic, src = measured_traffic(B, S)
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
-            "kernel": "tg::s4_kernel<STEP>" if S == 4 else f"tg::packed_kernel<{S},{256 if S == 25 else 64},STEP>",
+            "kernel": {4: "tg::s4_kernel<STEP>", 16: "tg::s16_step_kernel<STEP>", 9: "tg::packed_kernel<9,16,STEP>",
+                       25: "tg::packed_kernel<25,256,STEP>"}.get(S, "tg::slow_kernel<STEP>"),
             "bytes_per_launch": B * bytes_step(S), "avg_launch_us": round(per_launch_s * 1e6, 3),
             "note": ("achieved/frac price the ALGORITHMIC bytes 2S^3+3S+1 per step; in-place steps of the S>=9 kernels "
                      "skip the store of 16-byte chunks an action leaves unchanged, so `traffic` (PMC) can be lower")
@@ -283,8 +284,8 @@ def main():
                 also.append({"workload": f"S={s2} batch={b2} ({label})", "ok": r2["ok"],
                              "value": round(b2 * k2 / r2["wall_s"], 1), "unit": "steps/s",
                              "roofline": roofline(b2, s2, k2, r2["event_ms"])})
-            # the fused path, labelled separately (SURVEY 8d): K actions per launch, state stays on chip
             from mat_mul_amd import ops
+            # the fused path, labelled separately (SURVEY 8d): K actions per launch, state stays on chip
             for (s2, b2, k2) in [(4, 65536, 7), (16, 8192, 20)]:
                 tok, tgt = ops.gen_demos(b2, s2, k2, dev, seed=2)
                 st2 = ops.alloc_states(b2, s2, dev)

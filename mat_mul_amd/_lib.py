@@ -29,6 +29,7 @@ SIGNATURES = {
     "tg_last_error": [],
     "tg_debug_fallbacks": [_p],
     "tg_step_i8": [_p, _p, _p, _p, _p, _i64, _i, _i64, _i, _p],
+    "tg_step_sparse_i8": [_p, _p, _p, _p, _p, _i64, _i, _i64, _i, _p],
     "tg_step_many_i8": [_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _p],
     "tg_expand_i8": [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i, _p],
     "tg_done_i8": [_p, _p, _p, _i64, _i, _i64, _p],

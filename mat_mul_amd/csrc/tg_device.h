@@ -29,6 +29,17 @@ __device__ __forceinline__ int mul24_pinned(int a, int b) {
   return r;
 }
 
+// number of non-zero bytes of a dword: fold each byte onto its low bit, then popcount
+__device__ __forceinline__ int count_nonzero_bytes(uint32_t x) {
+  x |= x >> 4;
+  x |= x >> 2;
+  x |= x >> 1;
+  return __popc(x & 0x01010101u);
+}
+__device__ __forceinline__ int count_nonzero_bytes(const uint4& q) {
+  return count_nonzero_bytes(q.x) + count_nonzero_bytes(q.y) + count_nonzero_bytes(q.z) + count_nonzero_bytes(q.w);
+}
+
 // ---- team (sub-wave) reductions --------------------------------------------------------------
 
 // OR-reduce a predicate over the TS consecutive lanes (TS a power of two <= 64) this lane belongs to.

@@ -24,7 +24,9 @@ namespace tg {
 
 #define TG_MAX_ACTIONS 4096  // K / k / R per call
 
-enum Mode { STEP = 0, MANY = 1, EXPAND = 2, GENF = 3 };
+// STEPS: the in-place step that also maintains the per-game non-zero count (a.done_step doubles as
+// the int32 nnz array, in/out): kernels may then skip LOADING chunks an action does not touch.
+enum Mode { STEP = 0, MANY = 1, EXPAND = 2, GENF = 3, STEPS = 4 };
 
 // Debug aid: workgroups of the packed/rows kernels that fell back to the exact byte-wise form
 // (factors too large for the 16-bit path, or an int8 overflow in step_many).  A silent fallback is
@@ -54,8 +56,9 @@ struct ApplyArgs {
 // slow path: any S, any alignment.  One workgroup per game, one byte per thread-iteration.
 // =============================================================================================
 // One game (index b) by the whole workgroup.  nzf: TG_MAX_ACTIONS bytes of LDS (MANY only).
-template <int MODE>
+template <int MODE_>
 __device__ __forceinline__ void slow_game(const ApplyArgs& a, int64_t b, uint8_t* nzf) {
+  constexpr int MODE = (MODE_ == STEPS) ? STEP : MODE_;  // STEPS: a step plus an exact recount of nnz
   const int S = a.S, S2 = S * S, N = S2 * S, A3 = 3 * S;
   const int tid = threadIdx.x;
   const int8_t* tok = a.actions + b * a.nact * A3;
@@ -91,7 +94,7 @@ __device__ __forceinline__ void slow_game(const ApplyArgs& a, int64_t b, uint8_t
     }
     const int8_t* src = (MODE == GENF) ? nullptr : a.in + b * a.in_stride;
     int8_t* dst = a.out + b * a.out_stride;
-    int nz = 0, ovf = 0;
+    int nz = 0, ovf = 0, cnt = 0;
     for (int e = tid; e < N; e += kBlock) {
       const int i = e / S2, r = e - i * S2, j = r / S, l = r - j * S;
       int acc = (MODE == GENF) ? 0 : src[e];
@@ -111,6 +114,16 @@ __device__ __forceinline__ void slow_game(const ApplyArgs& a, int64_t b, uint8_t
       if constexpr (MODE == GENF) ovf |= (acc + 128);
       dst[e] = static_cast<int8_t>(acc);
       nz |= acc & 255;
+      if constexpr (MODE_ == STEPS) cnt += (acc & 255) != 0;
+    }
+    if constexpr (MODE_ == STEPS) {  // workgroup sum through an LDS word (nzf is 4-byte aligned)
+      int* total = reinterpret_cast<int*>(nzf);
+      __syncthreads();
+      if (tid == 0) *total = 0;
+      __syncthreads();
+      if (cnt) atomicAdd(total, cnt);
+      __syncthreads();
+      if (tid == 0) a.done_step[b] = *total;
     }
     nz = __syncthreads_or(nz);
     ovf = __syncthreads_or(ovf & ~255);
@@ -130,7 +143,7 @@ __device__ __forceinline__ void slow_game(const ApplyArgs& a, int64_t b, uint8_t
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void slow_kernel(ApplyArgs a) {
-  __shared__ uint8_t nzf[MODE == MANY ? TG_MAX_ACTIONS : 4];
+  __shared__ __attribute__((aligned(4))) uint8_t nzf[MODE == MANY ? TG_MAX_ACTIONS : 4];
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) slow_game<MODE>(a, b, nzf);
 }
 
@@ -456,10 +469,10 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
   if constexpr (MODE != GENF) pk = *reinterpret_cast<const uint4*>(in_blk + in_off);
   int ovf = 0;
 
-  if constexpr (MODE == STEP || MODE == MANY || MODE == GENF) {
+  if constexpr (MODE == STEP || MODE == STEPS || MODE == MANY || MODE == GENF) {
     int8_t* out_blk = a.out + g0 * a.out_stride;
     const uint32_t out_off = __umul24(lg, static_cast<uint32_t>(a.out_stride)) + 16u * q;
-    if constexpr (MODE == STEP) {
+    if constexpr (MODE == STEP || MODE == STEPS) {
       const S4Factors f = s4_factors<true>(tok, q, a.shift);
       int acc[16], chg = 0;
       uint32_t nz = 0;
@@ -474,6 +487,12 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
       if (q == 0 && live) {
         (a.done + g0)[lg] = any_nz ? 0 : 1;
         if (a.overflow && any_ovf) (a.overflow + g0)[lg] = 1;
+      }
+      if constexpr (MODE == STEPS) {  // S=4 reads the whole game anyway: nnz is simply recounted
+        int cnt = count_nonzero_bytes(pk);
+        cnt += __shfl_xor(cnt, 1);
+        cnt += __shfl_xor(cnt, 2);
+        if (q == 0 && live) (a.done_step + g0)[lg] = cnt;
       }
     } else {
       // exact 32-bit form: GENF always; MANY for teams the lattice form below hands over
@@ -598,19 +617,94 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
 }
 
 // =============================================================================================
+// S = 16 single step, register only.  One wavefront per game; lane = (r, j) owns the four rows
+// (i = r + 4n, j), n = 0..3, i.e. chunks lane + 64 n.  The game's 48 tokens come straight into
+// registers (u and w as uniform dwordx4 loads, v_j as a byte), so there is no LDS staging and no
+// workgroup barrier: the wavefront's dependency chain is ONE memory round trip, arithmetic, stores.
+// (The staged packed_kernel needs three barriers; at S = 16 the step is bound by that chain per
+// wavefront, not by bandwidth -- see DESIGN.md.)  Factors beyond the 16-bit path's range are handled
+// by the same wavefront in 32-bit.  Requires 16-byte aligned state and actions.
+// =============================================================================================
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void s16_step_kernel(ApplyArgs a) {
+  static_assert(MODE == STEP, "s16_step_kernel: single step only");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t g = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave;
+  const bool live = g < a.B;
+  if (!live) g = a.B - 1;
+  const int8_t* tok = a.actions + g * 48;
+  const int8_t* src = a.in + g * a.in_stride + 16 * lane;
+  // every load of the wavefront is issued before anything is used
+  uint4 par[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) par[n] = *reinterpret_cast<const uint4*>(src + 1024 * n);
+  const uint4 uq = *reinterpret_cast<const uint4*>(tok);
+  const uint4 wq = *reinterpret_cast<const uint4*>(tok + 32);
+  const int vj = tok[16 + (lane & 15)] - a.shift;
+  const int chk = tok[lane < 48 ? lane : 47] - a.shift;  // lane t checks token t
+  const int r = lane >> 4;
+  const uint32_t ud[4] = {uq.x, uq.y, uq.z, uq.w};
+  int ui[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) ui[n] = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(ud[n]), 8 * r, 8);  // -(u_i)
+  const bool big = __ballot(chk > 31 || chk < -31) != 0;  // wave-uniform
+  uint32_t nz = 0, ovf = 0;
+  uint4 res[4];
+  if (!big) {
+    const uint32_t shp = __builtin_amdgcn_perm(static_cast<uint32_t>(a.shift), static_cast<uint32_t>(a.shift), 0x05040100u);
+    uint32_t wp[8];
+    unpack_pairs(wq, wp);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int uv = mul24_pinned(ui[n], vj);
+      const uint32_t pr = __builtin_amdgcn_perm(static_cast<uint32_t>(uv), static_cast<uint32_t>(uv), 0x05040100u);
+      uint32_t A[8];
+      unpack_pairs(par[n], A);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) A[p] = pk_mad_i16(pr, wp[p], A[p]);
+      res[n] = pack_pairs(A, nz, ovf);
+    }
+    ovf &= 0xFF00FF00u;
+  } else {  // exact 32-bit form for this game (factors too large for int16 products)
+    if (lane == 0) atomicAdd(&g_fallback_workgroups, 1ull);
+    const uint32_t wd[4] = {wq.x, wq.y, wq.z, wq.w};
+    int o32 = 0;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int uv = ui[n] * vj;
+      int acc[16];
+      unpack16(par[n], acc);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[t] += uv * (sbyte(wd[t >> 2], t & 3) - a.shift);
+      res[n] = pack16(acc, nz, o32);
+    }
+    ovf = static_cast<uint32_t>(o32) & ~255u;
+  }
+  const bool inplace = a.in == a.out;
+  int8_t* dst = a.out + g * a.out_stride + 16 * lane;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const bool same = inplace && res[n].x == par[n].x && res[n].y == par[n].y && res[n].z == par[n].z &&
+                      res[n].w == par[n].w;  // untouched rows need no store in place
+    if (live && !same) *reinterpret_cast<uint4*>(dst + 1024 * n) = res[n];
+  }
+  const bool any_nz = __ballot(nz != 0) != 0;
+  const bool any_ovf = __ballot(ovf != 0) != 0;
+  if (lane == 0 && live) {
+    a.done[g] = any_nz ? 0 : 1;
+    if (a.overflow && any_ovf) a.overflow[g] = 1;
+  }
+}
+
+// =============================================================================================
 // terminal check / nnz, and reset
 // =============================================================================================
 
 // Terminal check + nnz.  A team of `lpg` consecutive lanes (power of two <= 64, chosen on the host
 // so that small games do not waste a wavefront: S=4 -> 4 lanes, 16 games per wavefront) owns one
 // game; 16-byte loads when the layout allows it (vec16), bytes otherwise.
-__device__ __forceinline__ int count_nonzero_bytes(uint32_t x) {
-  x |= x >> 4;
-  x |= x >> 2;
-  x |= x >> 1;
-  return __popc(x & 0x01010101u);  // each byte folded onto its low bit
-}
-
 __global__ __launch_bounds__(kBlock) void done_kernel(const int8_t* state, uint8_t* done, int32_t* nnz,
                                                       int64_t B, int N, int64_t stride, int vec16, int lpg) {
   const int lt = threadIdx.x & (lpg - 1);
@@ -626,8 +720,7 @@ __global__ __launch_bounds__(kBlock) void done_kernel(const int8_t* state, uint8
       body = N & ~15;
       for (int e = 16 * lt; e < body; e += 16 * lpg) {
         const uint4 q = *reinterpret_cast<const uint4*>(p + e);
-        cnt += count_nonzero_bytes(q.x) + count_nonzero_bytes(q.y) + count_nonzero_bytes(q.z) +
-               count_nonzero_bytes(q.w);
+        cnt += count_nonzero_bytes(q);
       }
     }
     for (int e = body + lt; e < N; e += lpg) cnt += p[e] != 0;
@@ -745,7 +838,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
   if constexpr (MODE == MANY) {
     flim = 127;  // lattice form (tg_packed.h): u*v and 256*w must be representable in int16
   } else {
-    const int64_t n = (MODE == GENF) ? a.nact : 1;
+    const int64_t n = (MODE == GENF) ? a.nact : 1;  // STEP, STEPS, EXPAND: one action per result
     while (flim < 31 && static_cast<int64_t>(flim + 1) * (flim + 1) * (flim + 1) * n <= 32000) ++flim;
   }
   static const bool force_i32 = getenv("TG_FORCE_I32") != nullptr;  // A/B switch for measurements
@@ -781,6 +874,16 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
     }
   }
 #undef TG_ROWS
+  static const bool no_s16 = getenv("TG_NO_S16_DIRECT") != nullptr;  // A/B switch for measurements
+  if constexpr (MODE == STEP) {
+    if (al && a.S == 16 && aligned16(a.actions) && !force_i32 && !no_s16) {
+      const int64_t blocks = (B + 3) / 4;
+      if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
+      (void)hipGetLastError();
+      hipLaunchKernelGGL((s16_step_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+      return check_launch(fn);
+    }
+  }
   if (al && flim >= 1 && !force_i32) {
     // S=9: a game is only 46 chunks, so a wavefront takes FOUR games (teams of 16 lanes, 9 active, 6
     // chunks per lane): measured 0.48 of the HBM peak at 2^19 games against 0.43 (TS=32) and 0.29 (TS=64)
@@ -789,9 +892,11 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
     if (a.S == 25) TG_PACKED(25, 256);
   }
 #undef TG_PACKED
-  if (al && a.S == 9) TG_TEAM(9, 64);
-  if (al && a.S == 16) TG_TEAM(16, 64);
-  if (al && a.S == 25) TG_TEAM(25, 256);
+  if constexpr (MODE != STEPS) {  // the 32-bit cursor kernels (A/B reference) have no nnz-carrying step
+    if (al && a.S == 9) TG_TEAM(9, 64);
+    if (al && a.S == 16) TG_TEAM(16, 64);
+    if (al && a.S == 25) TG_TEAM(25, 256);
+  }
 #undef TG_TEAM
   (void)hipGetLastError(); hipLaunchKernelGGL((slow_kernel<MODE>), dim3(capped_grid(B)), dim3(kBlock), 0, st, a);
   return check_launch(fn);
@@ -822,6 +927,16 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
   tg::ApplyArgs a{state_in, state_out, actions, done, nullptr, nullptr, overflow, B,
                   game_stride_bytes, game_stride_bytes, S, 1, shift};
   return launch_apply<tg::STEP>("tg_step_i8", a, static_cast<hipStream_t>(stream));
+}
+
+int tg_step_sparse_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_t* done, uint8_t* overflow,
+                      int64_t B, int S, int64_t game_stride_bytes, int shift, tg_stream_t stream) {
+  if (int rc = validate_common("tg_step_sparse_i8", B, S, game_stride_bytes)) return rc;
+  if (B && (!state || !actions || !nnz || !done)) return fail(TG_ERR_INVALID, "tg_step_sparse_i8: null pointer");
+  if (reinterpret_cast<uintptr_t>(nnz) & 3) return fail(TG_ERR_INVALID, "tg_step_sparse_i8: nnz must be 4-byte aligned");
+  tg::ApplyArgs a{state, state, actions, done, nnz, nullptr, overflow, B,
+                  game_stride_bytes, game_stride_bytes, S, 1, shift};
+  return launch_apply<tg::STEPS>("tg_step_sparse_i8", a, static_cast<hipStream_t>(stream));
 }
 
 int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,

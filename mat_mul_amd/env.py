@@ -26,7 +26,8 @@ class TensorGameEnv:
     """
 
     def __init__(self, batch_size: int, dim_3d: int, device="cuda", shift: int = 1,
-                 track_overflow: bool = True, game_id_offset: int = 0, dim_t: int = 1):
+                 track_overflow: bool = True, game_id_offset: int = 0, dim_t: int = 1,
+                 incremental: bool = False):
         self.B, self.S, self.shift = int(batch_size), int(dim_3d), int(shift)
         self.T = int(dim_t)  # history depth (reference --dim_t, training.py:75); 1 = head only
         self.device = torch.device(device)
@@ -37,6 +38,11 @@ class TensorGameEnv:
         # slot, so the reference's history shift (act.py:271-274) is a pointer bump, not a copy
         self.ring = ops.alloc_ring(self.B, self.S, self.T, self.device)
         self.head = 0
+        # incremental=True (dim_t == 1 only): the env carries every game's non-zero count, and a step then
+        # touches only the chunks its action changes (tg_step_sparse_i8) instead of the whole state
+        self.incremental = bool(incremental) and self.T == 1
+        self._nnz = torch.zeros((self.B,), dtype=torch.int32, device=self.device) if self.incremental else None
+        self._nnz_valid = False
         self.done = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
         self.overflow = torch.zeros((self.B,), dtype=torch.uint8, device=self.device) if track_overflow else None
         self.t = 0
@@ -82,6 +88,7 @@ class TensorGameEnv:
         if self.overflow is not None:
             self.overflow.zero_()
         self.t = 0
+        self._nnz_valid = False
         return self.state
 
     # -- step -------------------------------------------------------------------------------
@@ -90,6 +97,13 @@ class TensorGameEnv:
         converted with a range check).  Returns (state, done)."""
         if actions.dtype != torch.int8:
             actions = ops.as_tokens(actions, self.device)
+        if self.incremental:
+            if not self._nnz_valid:  # after reset() / step_many(): recount once
+                self._nnz.copy_(ops.done(self.state, want_nnz=True)[1])
+                self._nnz_valid = True
+            ops.step_sparse(self.state, actions, self._nnz, done=self.done, overflow=self.overflow, shift=self.shift)
+            self.t += 1
+            return self.state, self.done
         nxt = (self.head + 1) % self.T
         ops.step(self.ring[:, self.head], actions, out=self.ring[:, nxt], done=self.done, overflow=self.overflow,
                  shift=self.shift)
@@ -104,6 +118,7 @@ class TensorGameEnv:
         if self.T > 1:
             raise TensorGameError("step_many", -1, "step_many keeps no history; use step() when dim_t > 1")
         _, done_step = ops.step_many(self.state, actions, out=self.state, overflow=self.overflow, shift=self.shift)
+        self._nnz_valid = False
         self.t += actions.shape[1]
         return self.state, done_step
 
@@ -126,6 +141,8 @@ class TensorGameEnv:
         return -ops.slice_rank(self.state)
 
     def nnz(self) -> torch.Tensor:
+        if self.incremental and self._nnz_valid:
+            return self._nnz
         return ops.done(self.state, want_nnz=True)[1]
 
     def any_overflow(self) -> bool:

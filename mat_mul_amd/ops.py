@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import TG_MAX_ACTIONS, TG_MAX_S, TG_MAX_VALUES, TensorGameError, call
 
 __all__ = [
-    "step", "prepare_step", "step_many", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
+    "step", "step_sparse", "prepare_step", "step_many", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
     "gen_demos", "sample_basis", "change_basis", "as_tokens", "categorical_thresholds",
     "alloc_states", "alloc_ring", "emit_frames", "state_hash", "slice_rank",
 ]
@@ -114,6 +114,27 @@ def step(state, actions, out=None, done=None, overflow=None, shift: int = 1):
         call("tg_step_i8", _ptr(state), _ptr(out), _ptr(actions), _ptr(done), _ptr(overflow),
              B, S, stride, int(shift), _stream(dev))
     return out, done
+
+
+def step_sparse(state, actions, nnz, done=None, overflow=None, shift: int = 1):
+    """The in-place step for a caller that carries the per-game non-zero count: ``nnz`` (int32 (B,),
+    exact on entry, updated in place) lets the kernel skip loading and storing every chunk the action
+    does not touch.  Same results as ``step(state, actions, out=state)``; done[b] = (nnz[b] == 0).
+    Returns (state, done)."""
+    B, S, stride = _state_layout(state, "state")
+    dev = state.device
+    actions = _tokens(actions, (B,), S, dev, "actions")
+    nnz = _flag(nnz, (B,), torch.int32, dev, "nnz")
+    if nnz is None:
+        raise TensorGameError("step_sparse", -1, "nnz (int32 (B,)) is required; ops.done(state, want_nnz=True) computes it")
+    if done is None:
+        done = torch.empty((B,), dtype=torch.uint8, device=dev)
+    done = _flag(done, (B,), torch.uint8, dev, "done")
+    overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
+    with torch.cuda.device(dev):
+        call("tg_step_sparse_i8", _ptr(state), _ptr(actions), _ptr(nnz), _ptr(done), _ptr(overflow),
+             B, S, stride, int(shift), _stream(dev))
+    return state, done
 
 
 def prepare_step(state, actions_seq, done, overflow=None, shift: int = 1):

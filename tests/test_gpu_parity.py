@@ -759,3 +759,42 @@ def test_no_out_of_bounds_writes():
                 torch.cuda.synchronize()
                 check_flat(xbuf, "emit_frames")
                 check_flat(scbuf, "emit_frames scalars")
+
+
+@pytest.mark.parametrize("S,B", [(4, 70), (9, 33), (16, 12), (25, 5), (6, 9), (16, 1)])
+def test_step_sparse_rollout_matches_dense(S, B):
+    """tg_step_sparse_i8 over a multi-step rollout: state, done and the carried nnz equal the oracle at every
+    step -- sparse, dense and wide-factor actions, games that terminate, games that overflow."""
+    rng = np.random.default_rng(S * 11 + B)
+    K = 9
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, K, 3 * S)).astype(np.int8)
+    ac[:, 3] = rng.integers(0, 3, size=(B, 3 * S))                       # a dense action
+    ac[1::3, 5] = rng.integers(-3, 6, size=ac[1::3, 5].shape)            # wide factors
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    st[::4] = O.gen_from_factors_i8(ac[::4, :4])[0]                      # these reach zero after step 3
+    st[2::5] = rng.choice([-128, 127, 0], size=st[2::5].shape)           # these overflow
+    for layout in ("padded", "packed"):
+        t = padded(st) if layout == "padded" else dev(st)
+        nnz = ops.done(t, want_nnz=True)[1]
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        cur, want_ovf = st.copy(), np.zeros(B, np.uint8)
+        for k in range(K):
+            cur, want_done, o = O.step_i8(cur, ac[:, k])
+            want_ovf |= o
+            out, done = ops.step_sparse(t, dev(ac[:, k]), nnz, overflow=ovf)
+            assert out.data_ptr() == t.data_ptr()
+            assert np.array_equal(host(t), cur), (S, layout, k)
+            assert np.array_equal(host(done), want_done), (S, layout, k)
+            assert np.array_equal(host(nnz), O.nnz_per_game(cur)), (S, layout, k)
+            assert np.array_equal(host(ovf), want_ovf), (S, layout, k)
+        assert want_ovf.any() or B == 1
+    env = TensorGameEnv(B, S, DEV, incremental=True)
+    env.reset(dev(st))
+    cur = st.copy()
+    for k in range(4):
+        cur, want_done, _ = O.step_i8(cur, ac[:, k])
+        state, done = env.step(dev(ac[:, k]))
+        assert np.array_equal(host(state), cur) and np.array_equal(host(done), want_done)
+        assert np.array_equal(host(env.nnz()), O.nnz_per_game(cur))
+    idx = [b for b in range(0, B, 4) if b % 5 != 2]                       # terminating games not overwritten above
+    assert host(env.done)[idx].all()
