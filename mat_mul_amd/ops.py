@@ -85,12 +85,13 @@ def as_tokens(actions, device=None, check: bool = True) -> torch.Tensor:
     return t.contiguous()
 
 
-def alloc_states(B: int, S: int, device, pad_to: int = 16) -> torch.Tensor:
-    """Zeroed int8 (B,S,S,S) states whose game stride is S^3 rounded up to ``pad_to`` bytes
-    (16 keeps every game on the dwordx4 fast path; S=25 -> 15632)."""
+def alloc_states(B: int, S: int, device, pad_to: int = 16, zero: bool = True) -> torch.Tensor:
+    """int8 (B,S,S,S) states whose game stride is S^3 rounded up to ``pad_to`` bytes (16 keeps every
+    game on the dwordx4 fast path; S=25 -> 15632).  Zero-filled unless ``zero=False`` (outputs that a
+    kernel overwrites completely; the padding bytes are never read)."""
     n = S ** 3
     stride = -(-n // pad_to) * pad_to
-    buf = torch.zeros((B, stride), dtype=torch.int8, device=device)
+    buf = (torch.zeros if zero else torch.empty)((B, stride), dtype=torch.int8, device=device)
     return buf[:, :n].unflatten(1, (S, S, S))
 
 
@@ -197,7 +198,7 @@ def expand(state, actions, out=None, done=None, changed=None, overflow=None, shi
     k = actions.shape[1]
     actions = _tokens(actions, (B, k), S, dev, "actions")
     if out is None:
-        out = alloc_states(B * k, S, dev).unflatten(0, (B, k))
+        out = alloc_states(B * k, S, dev, zero=False).unflatten(0, (B, k))
     if out.dtype != torch.int8 or tuple(out.shape) != (B, k, S, S, S) or out.device != dev:
         raise TensorGameError("expand", -1, f"out must be int8 {(B, k, S, S, S)} on {dev}")
     _, _, ostride = _state_layout(out.flatten(0, 1), "out")
@@ -258,7 +259,7 @@ def gen_from_factors(actions, S: int, out=None, overflow=None, shift: int = 1):
     dev = actions.device
     actions = _tokens(actions, (B, R), S, dev, "actions")
     if out is None:
-        out = alloc_states(B, S, dev)
+        out = alloc_states(B, S, dev, zero=False)
     Bo, So, stride = _state_layout(out, "out")
     if (Bo, So) != (B, S) or out.device != dev:
         raise TensorGameError("gen_from_factors", -1, "out shape/device mismatch")
@@ -300,7 +301,7 @@ def gen_demos(B: int, S: int, R: int, device, values=(-1, 0, 1), probs=(0.15, 0.
     dev = torch.device(device)
     thr, vals, thr_p, val_p, nv = _dist(values, probs, "gen_demos")
     if target is None:
-        target = alloc_states(B, S, dev)
+        target = alloc_states(B, S, dev, zero=False)
     Bo, So, stride = _state_layout(target, "target")
     if actions is None:
         actions = torch.empty((B, R, 3 * S), dtype=torch.int8, device=dev)
