@@ -186,3 +186,22 @@ def test_next_rows_oracle(golden):
     strings = ["_".join(map(str, x.reshape(-1))) for x in s]      # the reference's key (utils.py:164-169)
     assert len(set(h.tolist())) == len(set(strings))              # equal keys <=> equal states on all 448
     assert len({(a, b) for a, b in zip(h.tolist(), strings)}) == len(set(strings))
+
+
+def test_notebook_known_answers(golden):
+    """notebooks/strassen_example.ipynb: the printed Strassen tensor (cell 5), the token table (cell 4),
+    the 448-pair count (cell 8) and the outer-product == einsum check (cells 14-17)."""
+    g = golden("strassen")
+    t = g["tensor"]
+    ones = {(0, 0, 0), (0, 1, 1), (1, 2, 0), (1, 3, 1), (2, 0, 2), (2, 1, 3), (3, 2, 2), (3, 3, 3)}   # cell 5 printout
+    assert {tuple(ix) for ix in np.argwhere(t == 1)} == ones and int(np.abs(t).sum()) == 8
+    assert g["tokens"].tolist() == [[2, 1, 1, 2, 2, 1, 1, 2, 2, 1, 1, 2], [1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 2, 0],
+                                    [2, 1, 1, 1, 1, 2, 1, 0, 1, 2, 1, 2], [1, 1, 1, 2, 0, 1, 2, 1, 2, 1, 2, 1],
+                                    [2, 2, 1, 1, 1, 1, 1, 2, 0, 2, 1, 1], [0, 1, 2, 1, 2, 2, 1, 1, 1, 1, 1, 2],
+                                    [1, 2, 1, 0, 1, 1, 2, 2, 2, 1, 1, 1]]                                 # cell 4 printout
+    assert len(g["ds_states"]) == 448                                                                     # cell 8
+    for u, v, w in zip(g["uu"], g["vv"], g["ww"]):                                                        # cells 14-17
+        assert np.array_equal(O.uvw_to_tensor((u, v, w)), np.einsum("p,qr->pqr", u, np.outer(v, w)))
+    first = O.uvw_to_tensor((g["uu"][0], g["vv"][0], g["ww"][0]))                                          # cell 14 printout
+    assert {tuple(ix) for ix in np.argwhere(first == 1)} == {(0, 0, 0), (0, 0, 3), (0, 3, 0), (0, 3, 3),
+                                                             (3, 0, 0), (3, 0, 3), (3, 3, 0), (3, 3, 3)}
