@@ -233,10 +233,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
-    # Rehearsal switches (not used by the driver): TG_BENCH_SHARE_GPU=1 maps every rank onto the
-    # GPUs that exist (N ranks on a 1-GPU box), TG_BENCH_BACKEND=gloo replaces the RCCL control plane.
-    if os.environ.get("TG_BENCH_SHARE_GPU"):
-        local = local % torch.cuda.device_count()
+    # One process per GPU.  LOCAL_RANK is taken modulo the VISIBLE devices, which is the identity on a full
+    # node and maps every rank to device 0 when the launcher exposes one GPU per process (HIP_VISIBLE_DEVICES).
+    # Rehearsal only: TG_BENCH_BACKEND=gloo replaces the RCCL control plane (N ranks sharing a 1-GPU box).
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
