@@ -596,7 +596,7 @@ print("AB_OK")
 '''
 
 
-@pytest.mark.parametrize("env_name", ["TG_FORCE_I32", "TG_NO_ROWS"])
+@pytest.mark.parametrize("env_name", ["TG_FORCE_I32", "TG_NO_ROWS", "TG_NO_S16_DIRECT"])
 def test_ab_switch_paths_stay_exact(env_name, tmp_path):
     """The measurement switches (32-bit cursor kernels; packed chunks instead of rows) select
     kernels that the default dispatch no longer uses -- they must stay bit-exact too."""
