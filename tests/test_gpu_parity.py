@@ -615,8 +615,10 @@ def test_randomized_differential():
     vocabulary, shift, action count, mode -- every one compared bit for bit with the oracle."""
     rng = np.random.default_rng(20261004)
     vocabularies = [((0, 1, 2), 1), ((1, 2, 3), 2), ((0, 1, 2, 3, 4), 2), ((-1, 0, 1), 0), (tuple(range(-4, 7)), 1)]
+    import os
+    total_cases = int(os.environ.get("TG_RANDOM_CASES", "120"))   # raise for a one-off stress run
     n_cases = 0
-    for case in range(120):
+    for case in range(total_cases):
         S = int(rng.choice([1, 2, 3, 4, 4, 5, 7, 8, 9, 9, 12, 16, 16, 25, 25, 32]))
         B = int(rng.integers(1, 24 if S <= 16 else 6))
         K = int(rng.integers(1, 12))
@@ -654,7 +656,7 @@ def test_randomized_differential():
         assert np.array_equal(host(t), st) or mode == 3, "inputs must be untouched"
         assert np.array_equal(host(ops.state_hash(t)).view(np.uint64), O.state_hash(st))
         n_cases += 1
-    assert n_cases == 120
+    assert n_cases == total_cases
 
 
 def test_take_action_batched_greedy_step():
