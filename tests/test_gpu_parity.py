@@ -800,3 +800,25 @@ def test_step_sparse_rollout_matches_dense(S, B):
         assert np.array_equal(host(env.nnz()), O.nnz_per_game(cur))
     idx = [b for b in range(0, B, 4) if b % 5 != 2]                       # terminating games not overwritten above
     assert host(env.done)[idx].all()
+
+
+@pytest.mark.parametrize("S,B,R", [(25, 512, 64), (16, 1024, 20), (4, 4096, 7)])
+def test_cfg5_generate_in_random_basis_then_replay(S, B, R):
+    """BASELINE config 5 shape: targets generated in a random unimodular basis; replaying the EMITTED actions
+    (any order) takes every game that did not overflow to zero, and the tensor-level change of basis of the
+    plain target equals the factor-level one."""
+    P = ops.sample_basis(B, S, DEV, seed=31)
+    ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    tok, tgt = ops.gen_demos(B, S, R, DEV, seed=32, basis=P, overflow=ovf)
+    ok = ~ovf.bool()
+    assert int(ok.sum()) > B // 2
+    env = TensorGameEnv(B, S, DEV)
+    env.reset(tgt)
+    state, done_step = env.step_many(tok.flip(1).contiguous())
+    assert not bool(state[ok].any()) and bool((done_step[ok] >= 0).all())
+    assert not bool(env.overflow[ok].any())
+    plain_tok, plain_tgt = ops.gen_demos(B, S, R, DEV, seed=32)
+    ovf2 = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    moved = ops.change_basis(plain_tgt, P.to(torch.int32), overflow=ovf2)
+    both = ok & ~ovf2.bool()
+    assert torch.equal(moved[both], tgt[both])
