@@ -595,21 +595,67 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
   } else {  // EXPAND: child (g, k) lives at out + (g*nact + k) * out_stride
     int8_t* out_blk = a.out + g0 * a.nact * a.out_stride;
     const int64_t c0 = g0 * a.nact;
-    for (int k = 0; k < a.nact; ++k) {
-      const S4Factors f = s4_factors<true>(tok + 3 * k, q, a.shift);
+    // The parent slice stays in registers as 8 int16 pairs; a child costs 8 v_pk_mad_i16 and about 40
+    // VALU ops in all.  int16 products need |factor| <= 31; a child with larger factors is redone by
+    // its 4-lane team in 32-bit (child_i32).
+    uint32_t Pp[8];
+    unpack_pairs(pk, Pp);
+    const uint32_t shp = __builtin_amdgcn_perm(static_cast<uint32_t>(a.shift), static_cast<uint32_t>(a.shift), 0x05040100u);
+    int64_t child_off = static_cast<int64_t>(lg) * a.nact * a.out_stride + 16 * q;  // advanced by out_stride per child
+    int t0 = tok[0], t1 = tok[1], t2 = tok[2];
+    for (int k = 0; k < a.nact; ++k, child_off += a.out_stride) {
+      const uint32_t du = t0, dv = t1, dw = t2;
+      if (k + 1 < a.nact) {  // prefetch the next child's tokens
+        t0 = tok[3 * (k + 1)];
+        t1 = tok[3 * (k + 1) + 1];
+        t2 = tok[3 * (k + 1) + 2];
+      }
       const uint32_t child = static_cast<uint32_t>(lg) * static_cast<uint32_t>(a.nact) + k;  // < 64 * 4096
-      int acc[16], chg = 0, covf = 0;
-      uint32_t nz = 0;
-      unpack16(pk, acc);
-      s4_rank1(acc, f, chg);
-      const uint4 o = pack16(acc, nz, covf);
-      if (live) *reinterpret_cast<uint4*>(out_blk + static_cast<int64_t>(child) * a.out_stride + 16 * q) = o;
+      const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(du), 8 * q, 8);  // -(u_i)
+      const uint32_t yv = dv << 8, yw = dw << 8, yu = du << 8;
+      const uint32_t vA = pk_sub_i16(__builtin_amdgcn_perm(dv, yv, 0x0A050804u), shp);
+      const uint32_t vB = pk_sub_i16(__builtin_amdgcn_perm(dv, yv, 0x0B070906u), shp);
+      const uint32_t wA = pk_sub_i16(__builtin_amdgcn_perm(dw, yw, 0x0A050804u), shp);
+      const uint32_t wB = pk_sub_i16(__builtin_amdgcn_perm(dw, yw, 0x0B070906u), shp);
+      const uint32_t uA = pk_sub_i16(__builtin_amdgcn_perm(du, yu, 0x0A050804u), shp);
+      const uint32_t uB = pk_sub_i16(__builtin_amdgcn_perm(du, yu, 0x0B070906u), shp);
+      // range: every factor of the child in [-31, 31]  <=>  (f + 31) <= 62 per half; the test is on
+      // (f + 32) & ~63 being zero, which admits exactly [-32, 31] (32^3 still fits int16)
+      const uint32_t rng = (pk_add_u16(uA, 0x00200020u) | pk_add_u16(uB, 0x00200020u) | pk_add_u16(vA, 0x00200020u) |
+                            pk_add_u16(vB, 0x00200020u) | pk_add_u16(wA, 0x00200020u) | pk_add_u16(wB, 0x00200020u)) &
+                           0xFFC0FFC0u;
+      // null action <=> u, v or w is the zero vector (the whole vector, not this lane's slice)
+      const bool nonnull = ((uA | uB) != 0) && ((vA | vB) != 0) && ((wA | wB) != 0);
+      uint4 o;
+      uint32_t nz = 0, covf = 0;
+      if (rng == 0) {  // team-uniform: all four lanes see the same 12 tokens
+        const uint32_t uip = __builtin_amdgcn_perm(static_cast<uint32_t>(ui), static_cast<uint32_t>(ui), 0x05040100u);
+        const uint32_t uvA = pk_mul_lo_u16(vA, uip), uvB = pk_mul_lo_u16(vB, uip);
+        const uint32_t pr[4] = {__builtin_amdgcn_perm(uvA, uvA, 0x01000100u), __builtin_amdgcn_perm(uvA, uvA, 0x03020302u),
+                                __builtin_amdgcn_perm(uvB, uvB, 0x01000100u), __builtin_amdgcn_perm(uvB, uvB, 0x03020302u)};
+        uint32_t A[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          A[2 * j] = pk_mad_i16(pr[j], wA, Pp[2 * j]);
+          A[2 * j + 1] = pk_mad_i16(pr[j], wB, Pp[2 * j + 1]);
+        }
+        o = pack_pairs(A, nz, covf);
+        covf &= 0xFF00FF00u;
+      } else {  // exact 32-bit form for this child
+        const int cur[3] = {static_cast<int>(du), static_cast<int>(dv), static_cast<int>(dw)};
+        const S4Factors f = s4_factors<true>(cur, q, a.shift);
+        int acc[16], chg = 0, c32 = 0;
+        unpack16(pk, acc);
+        s4_rank1(acc, f, chg);
+        o = pack16(acc, nz, c32);
+        covf = static_cast<uint32_t>(c32) & ~255u;
+      }
+      if (live) *reinterpret_cast<uint4*>(out_blk + child_off) = o;
       const bool any_nz = team_any<4>(nz != 0);
-      const bool any_chg = team_any<4>(chg != 0);
-      const bool any_ovf = team_any<4>((covf & ~255) != 0);
+      const bool any_ovf = team_any<4>(covf != 0);
       if (q == 0 && live) {
         (a.done + c0)[child] = any_nz ? 0 : 1;
-        if (a.changed) (a.changed + c0)[child] = any_chg ? 1 : 0;
+        if (a.changed) (a.changed + c0)[child] = nonnull ? 1 : 0;
         if (a.overflow && any_ovf) (a.overflow + c0)[child] = 1;
       }
     }
