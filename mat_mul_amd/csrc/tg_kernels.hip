@@ -462,7 +462,8 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
   const int lg_raw = threadIdx.x >> 2, q = threadIdx.x & 3;
   const bool live = lg_raw < nlive;
   const int lg = live ? lg_raw : nlive - 1;  // dead lanes shadow the last live game, stores predicated off
-  const int* tok = reinterpret_cast<const int*>(a.actions + g0 * a.nact * 12) + lg * a.nact * 3;
+  const int nact = (MODE == STEP || MODE == STEPS) ? 1 : a.nact;  // the single-step entries pass 1
+  const int* tok = reinterpret_cast<const int*>(a.actions + g0 * nact * 12) + lg * nact * 3;
   const int8_t* in_blk = a.in + g0 * a.in_stride;
   const uint32_t in_off = __umul24(lg, static_cast<uint32_t>(a.in_stride)) + 16u * q;
   uint4 pk{0, 0, 0, 0};
@@ -473,12 +474,46 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
     int8_t* out_blk = a.out + g0 * a.out_stride;
     const uint32_t out_off = __umul24(lg, static_cast<uint32_t>(a.out_stride)) + 16u * q;
     if constexpr (MODE == STEP || MODE == STEPS) {
-      const S4Factors f = s4_factors<true>(tok, q, a.shift);
-      int acc[16], chg = 0;
-      uint32_t nz = 0;
-      unpack16(pk, acc);
-      s4_rank1(acc, f, chg);
-      pk = pack16(acc, nz, ovf);
+      // Packed form: the slice as 8 sign-extended int16 pairs, 8 saturating v_pk_mad_i16.  No range
+      // check on the factors is needed: with |factor| <= 255 (int8 token, |shift| <= 127, else the
+      // 32-bit form below) u*v is formed exactly and SATURATES beyond int16, and so does (u v) w + x, so every
+      // case the 16-bit form cannot represent ends outside [-128, 127] -- exactly the cases where the
+      // true result overflows int8 (|x| <= 128 cannot bring a saturated product back).  Those lanes
+      // redo their slice in 32-bit below (wrapped bytes + flag, as the contract wants); all others
+      // are exact.  ~55 VALU ops per lane instead of ~105: at cfg2 the four wavefronts of a SIMD
+      // all get their data at the same time, so the arithmetic is on the launch's critical path.
+      const uint32_t du = tok[0], dv = tok[1], dw = tok[2];
+      const uint32_t shp = (static_cast<uint32_t>(a.shift) & 0xFFFFu) | (static_cast<uint32_t>(a.shift) << 16);
+      const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(du), 8 * q, 8);  // -(u_i)
+      const uint32_t uip = __builtin_amdgcn_perm(static_cast<uint32_t>(ui), static_cast<uint32_t>(ui), 0x05040100u);
+      const uint32_t yv = dv << 8, yw = dw << 8;
+      const uint32_t vA = pk_sub_i16(__builtin_amdgcn_perm(dv, yv, 0x0A050804u), shp);  // (v0, v1)
+      const uint32_t vB = pk_sub_i16(__builtin_amdgcn_perm(dv, yv, 0x0B070906u), shp);  // (v2, v3)
+      const uint32_t wA = pk_sub_i16(__builtin_amdgcn_perm(dw, yw, 0x0A050804u), shp);  // (w0, w1)
+      const uint32_t wB = pk_sub_i16(__builtin_amdgcn_perm(dw, yw, 0x0B070906u), shp);  // (w2, w3)
+      const uint32_t uvA = pk_mad_i16_sat(vA, uip, 0u), uvB = pk_mad_i16_sat(vB, uip, 0u);
+      uint32_t A[8];
+      unpack_pairs(pk, A);
+      A[0] = pk_mad_i16_sat_lo(uvA, wA, A[0]);  // row j = 0: -u v0 in both halves
+      A[1] = pk_mad_i16_sat_lo(uvA, wB, A[1]);
+      A[2] = pk_mad_i16_sat_hi(uvA, wA, A[2]);  // j = 1
+      A[3] = pk_mad_i16_sat_hi(uvA, wB, A[3]);
+      A[4] = pk_mad_i16_sat_lo(uvB, wA, A[4]);  // j = 2
+      A[5] = pk_mad_i16_sat_lo(uvB, wB, A[5]);
+      A[6] = pk_mad_i16_sat_hi(uvB, wA, A[6]);  // j = 3
+      A[7] = pk_mad_i16_sat_hi(uvB, wB, A[7]);
+      uint32_t nz = 0, ovf16 = 0;
+      const uint4 in_slice = pk;
+      pk = pack_pairs(A, nz, ovf16);
+      const bool wide_shift = static_cast<unsigned>(a.shift + 127) > 254u;  // uniform; factors may exceed 255
+      if (__builtin_expect(wide_shift || (ovf16 & 0xFF00FF00u), 0)) {  // rare, per lane: exact 32-bit form of this slice
+        const S4Factors f = s4_factors<true>(tok, q, a.shift);
+        int acc[16], chg = 0;
+        nz = 0;
+        unpack16(in_slice, acc);
+        s4_rank1(acc, f, chg);
+        pk = pack16(acc, nz, ovf);
+      }
       // (skipping the store of untouched slices, as packed_kernel does in place, is SLOWER here: 16-byte
       // holes inside 64-byte games turn full-line writes into partial ones -- 2.83 -> 3.05 us at cfg2)
       if (live) *reinterpret_cast<uint4*>(out_blk + out_off) = pk;

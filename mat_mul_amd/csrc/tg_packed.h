@@ -109,6 +109,17 @@ __device__ __forceinline__ uint32_t pk_mad_i16_sat(uint32_t a, uint32_t b, uint3
   asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// the same with the LOW / HIGH half of `a` used for both halves of the product (VOP3P op_sel)
+__device__ __forceinline__ uint32_t pk_mad_i16_sat_lo(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t pk_mad_i16_sat_hi(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ uint32_t pk_lshl8_b16(uint32_t a) {
   uint32_t d;
   // the shift count is per half: an inline constant 8 would shift the low half only

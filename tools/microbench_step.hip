@@ -151,6 +151,108 @@ __global__ __launch_bounds__(BLOCK) void k_stepb(const uint4* in, uint4* out, co
   }
 }
 
+// copy + the three token dwords (no arithmetic): what the memory side of a step costs
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_copytok(const uint4* in, uint4* out, const int* tok, uint8_t* done, int B) {
+  const int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t < 4 * B) {
+    uint4 q = in[t];
+    const int g = t >> 2;
+    const int a = tok[g * 3], b = tok[g * 3 + 1], c = tok[g * 3 + 2];
+    out[t] = q;
+    if ((t & 3) == 0) done[g] = ((q.x | q.y | q.z | q.w) == 0) | ((a ^ b ^ c) == 0x7fffffff);
+  }
+}
+
+// packed int16 form: 8 saturating v_pk_mad_i16 on sign-extended pairs; no factor range checks
+// (saturation turns every inexact case into an int8 overflow, which is re-done in 32-bit)
+__device__ __forceinline__ uint32_t pkmad_lo(uint32_t a, uint32_t b, uint32_t c) {  // a.lo broadcast
+  uint32_t d;
+  asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t pkmad_hi(uint32_t a, uint32_t b, uint32_t c) {  // a.hi broadcast
+  uint32_t d;
+  asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t pkmul_sat(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_mad_i16 %0, %1, %2, 0 clamp" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t pksub(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t pkaddu(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_steppk(const uint4* in, uint4* out, const int* tok, uint8_t* done, int B) {
+  const int t0 = (blockIdx.x * BLOCK + threadIdx.x);
+  const int q = t0 & 3;
+  int g = t0 >> 2;
+  const bool live = g < B;
+  if (!live) g = B - 1;
+  const uint4 pk = in[g * 4 + q];
+  const uint32_t du = tok[g * 3], dv = tok[g * 3 + 1], dw = tok[g * 3 + 2];
+  const uint32_t shp = 0x00010001u;
+  const int ui = 1 - __builtin_amdgcn_sbfe((int)du, 8 * q, 8);
+  const uint32_t uip = __builtin_amdgcn_perm((uint32_t)ui, (uint32_t)ui, 0x05040100u);
+  const uint32_t yv = dv << 8, yw = dw << 8;
+  const uint32_t vA = pksub(__builtin_amdgcn_perm(dv, yv, 0x0A050804u), shp);
+  const uint32_t vB = pksub(__builtin_amdgcn_perm(dv, yv, 0x0B070906u), shp);
+  const uint32_t wA = pksub(__builtin_amdgcn_perm(dw, yw, 0x0A050804u), shp);
+  const uint32_t wB = pksub(__builtin_amdgcn_perm(dw, yw, 0x0B070906u), shp);
+  const uint32_t uvA = pkmul_sat(vA, uip), uvB = pkmul_sat(vB, uip);
+  const uint32_t x[4] = {pk.x, pk.y, pk.z, pk.w};
+  uint32_t A[8];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t y = x[d] << 8;
+    const uint32_t lo = __builtin_amdgcn_perm(x[d], y, 0x0A050804u), hi = __builtin_amdgcn_perm(x[d], y, 0x0B070906u);
+    const uint32_t uv = d < 2 ? uvA : uvB;
+    if (d & 1) {
+      A[2 * d] = pkmad_hi(uv, wA, lo);
+      A[2 * d + 1] = pkmad_hi(uv, wB, hi);
+    } else {
+      A[2 * d] = pkmad_lo(uv, wA, lo);
+      A[2 * d + 1] = pkmad_lo(uv, wB, hi);
+    }
+  }
+  uint32_t o[4], nz = 0, ovf = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    ovf |= pkaddu(A[2 * d], 0x00800080u) | pkaddu(A[2 * d + 1], 0x00800080u);
+    o[d] = __builtin_amdgcn_perm(A[2 * d + 1], A[2 * d], 0x06040200u);
+    nz |= o[d];
+  }
+  if (ovf & 0xFF00FF00u) {  // rare: exact 32-bit redo of this lane's slice
+    const int v[4] = {sbyte(dv, 0) - 1, sbyte(dv, 1) - 1, sbyte(dv, 2) - 1, sbyte(dv, 3) - 1};
+    const int w[4] = {sbyte(dw, 0) - 1, sbyte(dw, 1) - 1, sbyte(dw, 2) - 1, sbyte(dw, 3) - 1};
+    nz = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int uv = ui * v[j];
+      o[j] = pack4(uv * w[0] + sbyte(x[j], 0), uv * w[1] + sbyte(x[j], 1), uv * w[2] + sbyte(x[j], 2),
+                   uv * w[3] + sbyte(x[j], 3));
+      nz |= o[j];
+    }
+    done[0] = 2;  // stand-in for the overflow store
+  }
+  const uint64_t m = __ballot(nz != 0);
+  const int lane = threadIdx.x & 63;
+  const bool any = ((m >> (lane & ~3)) & 0xf) != 0;
+  if (live) {
+    out[g * 4 + q] = uint4{o[0], o[1], o[2], o[3]};
+    if (q == 0) done[g] = !any;
+  }
+}
+
 struct Variant {
   const char* name;
   void (*kern)(const uint4*, uint4*, const int*, uint8_t*, int);
@@ -175,7 +277,9 @@ int main(int argc, char** argv) {
   std::vector<Variant> vs = {
       {"empty  256thr x1", k_empty<256>, 256, 1},   {"empty 1024thr x1", k_empty<1024>, 1024, 1},
       {"copy   256thr x1", k_copy<256>, 256, 1},    {"copy  1024thr x1", k_copy<1024>, 1024, 1},
-      {"step32 256thr x1", k_step32<256, 1>, 256, 1}, {"step32 256thr x2", k_step32<256, 2>, 256, 2},
+      {"step32 256thr x1", k_step32<256, 1>, 256, 1}, {"steppk 256thr x1", k_steppk<256>, 256, 1},
+      {"copytok 256thr x1", k_copytok<256>, 256, 1},  {"steppk 512thr x1", k_steppk<512>, 512, 1},
+      {"step32 256thr x2", k_step32<256, 2>, 256, 2},
       {"step32 256thr x4", k_step32<256, 4>, 256, 4}, {"step32 512thr x1", k_step32<512, 1>, 512, 1},
       {"step32 1024thr x1", k_step32<1024, 1>, 1024, 1}, {"step32 1024thr x2", k_step32<1024, 2>, 1024, 2},
       {"step32 1024thr x4", k_step32<1024, 4>, 1024, 4},
@@ -183,6 +287,8 @@ int main(int argc, char** argv) {
       {"stepb  512thr x2", k_stepb<512, 2>, 512, 2}, {"stepb 1024thr x1", k_stepb<1024, 1>, 1024, 1},
       {"stepb 1024thr x2", k_stepb<1024, 2>, 1024, 2}, {"stepb 1024thr x4", k_stepb<1024, 4>, 1024, 4},
   };
+  const bool quick = argc > 3 && atoi(argv[3]) != 0;
+  if (quick) vs.resize(8);
   printf("B=%d games, %d launches per graph; algorithmic bytes per launch = %.2f MB\n", B, N, B * 141 / 1e6);
   for (int rep = 0; rep < 2; ++rep)
     for (auto& v : vs) {
@@ -249,6 +355,7 @@ int main(int argc, char** argv) {
     printf("product tg_step_i8 (overflow %s)  graph %.3f us/launch (%.0f GB/s alg)\n", rep ? "tracked" : "NULL",
            ms * 1e3 / N, B * 141.0 / (ms * 1e-3 / N) / 1e9);
   }
+  if (quick) return 0;
   // ---- split the batch into P independent chains inside ONE graph (fork/join by events) ----
   for (int P : {1, 2, 4, 8}) {
     CK(hipMemcpy(st, hs.data(), hs.size(), hipMemcpyHostToDevice));
@@ -289,6 +396,47 @@ int main(int argc, char** argv) {
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("product, %d independent chains of %d games: %.3f us per full-batch step (%.0f GB/s alg)\n", P, Bp,
+           ms * 1e3 / N, B * 141.0 / (ms * 1e-3 / N) / 1e9);
+  }
+  // ---- P separate graphs on P separate streams (one chain of half/quarter-batch launches each), replayed
+  //      concurrently: do the dependent-launch boundaries of different hardware queues overlap? ----
+  for (int P : {1, 2, 4}) {
+    CK(hipMemcpy(st, hs.data(), hs.size(), hipMemcpyHostToDevice));
+    std::vector<hipStream_t> ss(P);
+    std::vector<hipGraphExec_t> ges(P);
+    std::vector<hipEvent_t> ev(P);
+    const int Bp = B / P;
+    for (int p = 0; p < P; ++p) {
+      CK(hipStreamCreateWithFlags(&ss[p], hipStreamNonBlocking));
+      CK(hipEventCreateWithFlags(&ev[p], hipEventDisableTiming));
+      hipGraph_t g;
+      CK(hipStreamBeginCapture(ss[p], hipStreamCaptureModeThreadLocal));
+      for (int i = 0; i < N; ++i)
+        if (tg_step_i8((const int8_t*)st + (size_t)p * Bp * 64, (int8_t*)st + (size_t)p * Bp * 64,
+                       (const int8_t*)tok + (size_t)p * Bp * 12, done + (size_t)p * Bp, nullptr, Bp, 4, 64, 1, ss[p]))
+          return 1;
+      CK(hipStreamEndCapture(ss[p], &g));
+      CK(hipGraphInstantiate(&ges[p], g, nullptr, nullptr, 0));
+    }
+    hipEvent_t fork, e0, e1;
+    CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0, s));
+      CK(hipEventRecord(fork, s));
+      for (int p = 0; p < P; ++p) {
+        CK(hipStreamWaitEvent(ss[p], fork, 0));
+        CK(hipGraphLaunch(ges[p], ss[p]));
+        CK(hipEventRecord(ev[p], ss[p]));
+      }
+      for (int p = 0; p < P; ++p) CK(hipStreamWaitEvent(s, ev[p], 0));
+      CK(hipEventRecord(e1, s));
+      CK(hipStreamSynchronize(s));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    printf("product, %d graphs on %d streams (%d games each): %.3f us per full-batch step (%.0f GB/s alg)\n", P, P, Bp,
            ms * 1e3 / N, B * 141.0 / (ms * 1e-3 / N) / 1e9);
   }
   return 0;
