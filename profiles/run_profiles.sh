@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the default bench command (hipGraph replay), no CPU leg, headline workload only
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_graph -o bench_graph -- python3 $R/bench.py --no-cpu-baseline --no-also > $OUT/bench_graph.json 2> $OUT/bench_graph.err || exit 1
 # 1b. the same for BASELINE config 3 (S=16, B=8192)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_graph_S16 -o bench_graph_S16 -- python3 $R/bench.py --dim 16 --steps 504 --warmup 56 --no-cpu-baseline --no-also > $OUT/bench_graph_S16.json 2> $OUT/bench_graph_S16.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_graph_S16 -o bench_graph_S16 -- python3 $R/bench.py --dim 16 --steps 512 --warmup 64 --no-cpu-baseline --no-also > $OUT/bench_graph_S16.json 2> $OUT/bench_graph_S16.err || exit 1
 # 2. the same in eager mode (one ctypes launch per step)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_eager -o bench_eager -- python3 $R/bench.py --mode eager --no-cpu-baseline --no-also > $OUT/bench_eager.json 2> $OUT/bench_eager.err || exit 1
 # 3. HBM traffic counters, one pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass), eager, few steps

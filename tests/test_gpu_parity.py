@@ -193,6 +193,32 @@ def test_step_wide_tokens_and_overflow(S):
         assert host(sticky).all()
 
 
+@pytest.mark.parametrize("S", [4, 16, 9, 25, 3])
+def test_step_extreme_factors_full_int8_range(S):
+    """Tokens over the whole int8 range and shifts up to far beyond it: |u v| can pass 2^15 and
+    |u v w| 2^23.  The 16-bit kernels must hand exactly these cases to their 32-bit form: stored
+    bytes are the wrapped low bytes of the true result, and the flag is set iff it left int8."""
+    rng = np.random.default_rng(4242 + S)
+    B = 96
+    st = rng.integers(-128, 128, size=(B, S, S, S)).astype(np.int8)
+    for shift in (1, 127, -127, 128, 300, -1000):
+        ac = rng.integers(-128, 128, size=(B, 3 * S)).astype(np.int8)
+        zero_tok = np.int8(shift) if -128 <= shift <= 127 else None
+        if zero_tok is not None:
+            # plant zero factors: whole w (product vanishes although u v is huge), single entries elsewhere
+            ac[0::4, 2 * S:] = zero_tok
+            ac[1::4, :S] = np.where(rng.random((len(ac[1::4]), S)) < 0.7, zero_tok, ac[1::4, :S])
+            ac[2::4, S:2 * S] = np.where(rng.random((len(ac[2::4]), S)) < 0.7, zero_tok, ac[2::4, S:2 * S])
+            ac[3::4] = np.clip(ac[3::4].astype(int), shift - 2, shift + 2).astype(np.int8)  # small factors
+        want, want_done, want_ovf = O.step_i8(st, ac, shift=shift)
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        out, done = ops.step(padded(st), dev(ac), overflow=ovf, shift=shift)
+        assert np.array_equal(host(out), want), shift
+        assert np.array_equal(host(done), want_done) and np.array_equal(host(ovf), want_ovf), shift
+        if zero_tok is not None:
+            assert not want_ovf[0::4].any() and want_ovf.any()
+
+
 @pytest.mark.parametrize("S,B,K", [(4, 130, 7), (4, 5, 40), (9, 33, 12), (16, 9, 70), (25, 3, 130), (5, 6, 9), (2, 3, 3)])
 def test_step_many_matches_oracle(S, B, K):
     rng = np.random.default_rng(S * 31 + K)
