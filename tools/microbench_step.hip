@@ -151,6 +151,19 @@ __global__ __launch_bounds__(BLOCK) void k_stepb(const uint4* in, uint4* out, co
   }
 }
 
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+// copy with non-temporal stores / loads: does the end-of-kernel L2 write-back shrink when stores stream?
+template <int BLOCK, int NTL>
+__global__ __launch_bounds__(BLOCK) void k_copy_nt(const uint4* in, uint4* out, const int* tok, uint8_t* done, int B) {
+  const int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t < 4 * B) {
+    const v4u* src = reinterpret_cast<const v4u*>(in) + t;
+    v4u q = NTL ? __builtin_nontemporal_load(src) : *src;
+    __builtin_nontemporal_store(q, reinterpret_cast<v4u*>(out) + t);
+    if ((t & 3) == 0) done[t >> 2] = (q.x | q.y | q.z | q.w) == 0;
+  }
+}
+
 // copy + the three token dwords (no arithmetic): what the memory side of a step costs
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_copytok(const uint4* in, uint4* out, const int* tok, uint8_t* done, int B) {
@@ -253,6 +266,73 @@ __global__ __launch_bounds__(BLOCK) void k_steppk(const uint4* in, uint4* out, c
   }
 }
 
+struct FatArgs {  // the product's ApplyArgs layout: 96 bytes, the fields a step needs spread over it
+  const uint4* in; uint4* out; const int* tok; uint8_t* done; int* done_step; uint8_t* changed; uint8_t* overflow;
+  long long B, in_stride, out_stride; int S, nact, shift;
+};
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_steppk_fat(FatArgs a) {
+  const uint4* in = a.in; uint4* out = a.out; const int* tok = a.tok; uint8_t* done = a.done; const int B = (int)a.B;
+  const int t0 = (blockIdx.x * BLOCK + threadIdx.x);
+  const int q = t0 & 3;
+  int g = t0 >> 2;
+  const bool live = g < B;
+  if (!live) g = B - 1;
+  const uint4 pk = in[g * 4 + q];
+  const uint32_t du = tok[g * 3], dv = tok[g * 3 + 1], dw = tok[g * 3 + 2];
+  const uint32_t shp = ((uint32_t)a.shift & 0xffffu) | ((uint32_t)a.shift << 16);
+  const int ui = a.shift - __builtin_amdgcn_sbfe((int)du, 8 * q, 8);
+  const uint32_t uip = __builtin_amdgcn_perm((uint32_t)ui, (uint32_t)ui, 0x05040100u);
+  const uint32_t yv = dv << 8, yw = dw << 8;
+  const uint32_t vA = pksub(__builtin_amdgcn_perm(dv, yv, 0x0A050804u), shp);
+  const uint32_t vB = pksub(__builtin_amdgcn_perm(dv, yv, 0x0B070906u), shp);
+  const uint32_t wA = pksub(__builtin_amdgcn_perm(dw, yw, 0x0A050804u), shp);
+  const uint32_t wB = pksub(__builtin_amdgcn_perm(dw, yw, 0x0B070906u), shp);
+  const uint32_t uvA = pkmul_sat(vA, uip), uvB = pkmul_sat(vB, uip);
+  const uint32_t x[4] = {pk.x, pk.y, pk.z, pk.w};
+  uint32_t A[8];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t y = x[d] << 8;
+    const uint32_t lo = __builtin_amdgcn_perm(x[d], y, 0x0A050804u), hi = __builtin_amdgcn_perm(x[d], y, 0x0B070906u);
+    const uint32_t uv = d < 2 ? uvA : uvB;
+    if (d & 1) {
+      A[2 * d] = pkmad_hi(uv, wA, lo);
+      A[2 * d + 1] = pkmad_hi(uv, wB, hi);
+    } else {
+      A[2 * d] = pkmad_lo(uv, wA, lo);
+      A[2 * d + 1] = pkmad_lo(uv, wB, hi);
+    }
+  }
+  uint32_t o[4], nz = 0, ovf = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    ovf |= pkaddu(A[2 * d], 0x00800080u) | pkaddu(A[2 * d + 1], 0x00800080u);
+    o[d] = __builtin_amdgcn_perm(A[2 * d + 1], A[2 * d], 0x06040200u);
+    nz |= o[d];
+  }
+  if (ovf & 0xFF00FF00u) {  // rare: exact 32-bit redo of this lane's slice
+    const int v[4] = {sbyte(dv, 0) - 1, sbyte(dv, 1) - 1, sbyte(dv, 2) - 1, sbyte(dv, 3) - 1};
+    const int w[4] = {sbyte(dw, 0) - 1, sbyte(dw, 1) - 1, sbyte(dw, 2) - 1, sbyte(dw, 3) - 1};
+    nz = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int uv = ui * v[j];
+      o[j] = pack4(uv * w[0] + sbyte(x[j], 0), uv * w[1] + sbyte(x[j], 1), uv * w[2] + sbyte(x[j], 2),
+                   uv * w[3] + sbyte(x[j], 3));
+      nz |= o[j];
+    }
+    done[0] = 2;  // stand-in for the overflow store
+  }
+  const uint64_t m = __ballot(nz != 0);
+  const int lane = threadIdx.x & 63;
+  const bool any = ((m >> (lane & ~3)) & 0xf) != 0;
+  if (live) {
+    out[g * 4 + q] = uint4{o[0], o[1], o[2], o[3]};
+    if (q == 0) done[g] = !any;
+  }
+}
+
 struct Variant {
   const char* name;
   void (*kern)(const uint4*, uint4*, const int*, uint8_t*, int);
@@ -278,7 +358,8 @@ int main(int argc, char** argv) {
       {"empty  256thr x1", k_empty<256>, 256, 1},   {"empty 1024thr x1", k_empty<1024>, 1024, 1},
       {"copy   256thr x1", k_copy<256>, 256, 1},    {"copy  1024thr x1", k_copy<1024>, 1024, 1},
       {"step32 256thr x1", k_step32<256, 1>, 256, 1}, {"steppk 256thr x1", k_steppk<256>, 256, 1},
-      {"copytok 256thr x1", k_copytok<256>, 256, 1},  {"steppk 512thr x1", k_steppk<512>, 512, 1},
+      {"copytok 256thr x1", k_copytok<256>, 256, 1},  {"copy nt-store 256", k_copy_nt<256, 0>, 256, 1},
+      {"copy nt-ld+st 256", k_copy_nt<256, 1>, 256, 1},  {"steppk 512thr x1", k_steppk<512>, 512, 1},
       {"step32 256thr x2", k_step32<256, 2>, 256, 2},
       {"step32 256thr x4", k_step32<256, 4>, 256, 4}, {"step32 512thr x1", k_step32<512, 1>, 512, 1},
       {"step32 1024thr x1", k_step32<1024, 1>, 1024, 1}, {"step32 1024thr x2", k_step32<1024, 2>, 1024, 2},
@@ -288,7 +369,7 @@ int main(int argc, char** argv) {
       {"stepb 1024thr x2", k_stepb<1024, 2>, 1024, 2}, {"stepb 1024thr x4", k_stepb<1024, 4>, 1024, 4},
   };
   const bool quick = argc > 3 && atoi(argv[3]) != 0;
-  if (quick) vs.resize(8);
+  if (quick) vs.resize(10);
   printf("B=%d games, %d launches per graph; algorithmic bytes per launch = %.2f MB\n", B, N, B * 141 / 1e6);
   for (int rep = 0; rep < 2; ++rep)
     for (auto& v : vs) {
@@ -325,6 +406,30 @@ int main(int argc, char** argv) {
       CK(hipGraphExecDestroy(ge));
       CK(hipGraphDestroy(g));
     }
+  {
+    FatArgs fa{st, st, tok, done, nullptr, nullptr, nullptr, B, 64, 64, 4, 1, 1};
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipMemcpy(st, hs.data(), hs.size(), hipMemcpyHostToDevice));
+      hipGraph_t g;
+      hipGraphExec_t ge;
+      CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+      for (int i = 0; i < N; ++i) hipLaunchKernelGGL(k_steppk_fat<256>, dim3(4 * B / 256), dim3(256), 0, s, fa);
+      CK(hipStreamEndCapture(s, &g));
+      CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      CK(hipGraphLaunch(ge, s));
+      CK(hipStreamSynchronize(s));
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      CK(hipEventRecord(e0, s));
+      CK(hipGraphLaunch(ge, s));
+      CK(hipEventRecord(e1, s));
+      CK(hipStreamSynchronize(s));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep) printf("steppk 256thr, 96-byte kernarg struct: graph %.3f us/launch\n", ms * 1e3 / N);
+    }
+  }
   // the product entry point itself (libtensorgame.so), same harness; rep 2: a different token buffer every launch
   int* tok14;
   CK(hipMalloc(&tok14, (size_t)B * 12 * 14));
