@@ -11,7 +11,7 @@ CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB_PATH = LIB_DIR / "libtensorgame.so"
 SOURCES = [CSRC / "tg_kernels.hip", CSRC / "tg_gen.hip", CSRC / "tg_aux.hip"]
-HEADERS = [CSRC / "tg_device.h", CSRC / "tg_packed.h", CSRC / "tg_rows.h", PKG.parent / "include" / "tensor_game.h"]
+HEADERS = [CSRC / "tg_device.h", CSRC / "tg_packed.h", CSRC / "tg_rows.h", CSRC / "tg_mfma.h", PKG.parent / "include" / "tensor_game.h"]
 
 
 def _hipcc() -> str:
@@ -34,6 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         return LIB_PATH
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     cmd = [_hipcc(), "-O3", "-std=c++17", "-shared", "-fPIC", "--offload-arch=gfx950",
+           "-mllvm", "-amdgpu-mfma-vgpr-form",  # MFMA results in VGPRs (tg_mfma.h): no v_accvgpr moves
            "-Wall", "-Wno-unused-function", *map(str, SOURCES), "-o", str(LIB_PATH)]
     if verbose:
         print(" ".join(cmd))

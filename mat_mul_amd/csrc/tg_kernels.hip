@@ -414,6 +414,7 @@ __global__ __launch_bounds__(kBlock) void team_kernel(ApplyArgs a) {
 
 #include "tg_packed.h"
 #include "tg_rows.h"
+#include "tg_mfma.h"
 
 // =============================================================================================
 // S = 4 in registers: 4 lanes per game, lane q owns slice i = q (16 bytes = one dwordx4).
@@ -945,6 +946,32 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
                        ldsb, st, a, flim, at);                                                  \
     return check_launch(fn);                                                                    \
   } while (0)
+  static const bool no_mfma = getenv("TG_NO_MFMA") != nullptr;  // A/B switch for measurements
+  if constexpr (MODE == GENF) {
+    // the accumulation over R is a dense contraction: matrix cores (tg_mfma.h); u*v must fit int8 (checked
+    // on device, per game), the transposed factors of one game must fit LDS
+    if (aligned16(a.out) && a.out_stride % 16 == 0 && a.nact <= 256 && !force_i32 && !no_mfma) {
+#define TG_MFMA(S_)                                                                              \
+  do {                                                                                           \
+    const int Rp = (a.nact + 31) & ~31;                                                          \
+    (void)hipGetLastError();                                                                     \
+    if (Rp == 32)                                                                                \
+      hipLaunchKernelGGL((genf_mfma_kernel<S_, 1>), dim3(capped_grid(B)), dim3(kBlock),          \
+                         mfma_lds_bytes<S_>(Rp), st, a, Rp);                                     \
+    else if (Rp == 64)                                                                           \
+      hipLaunchKernelGGL((genf_mfma_kernel<S_, 2>), dim3(capped_grid(B)), dim3(kBlock),          \
+                         mfma_lds_bytes<S_>(Rp), st, a, Rp);                                     \
+    else                                                                                         \
+      hipLaunchKernelGGL((genf_mfma_kernel<S_, 0>), dim3(capped_grid(B)), dim3(kBlock),          \
+                         mfma_lds_bytes<S_>(Rp), st, a, Rp);                                     \
+    return check_launch(fn);                                                                     \
+  } while (0)
+      if (a.S == 9) TG_MFMA(9);
+      if (a.S == 16) TG_MFMA(16);
+      if (a.S == 25) TG_MFMA(25);
+#undef TG_MFMA
+    }
+  }
   static const bool no_rows = getenv("TG_NO_ROWS") != nullptr;  // A/B switch for measurements
   if constexpr (MODE == MANY || MODE == GENF) {
     // odd S, several actions: each lane owns whole rows (tg_rows.h); the LDS transposition is

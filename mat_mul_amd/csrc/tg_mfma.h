@@ -1,0 +1,230 @@
+// tg_mfma.h -- the generator's accumulation on the matrix cores (included by tg_kernels.hip).
+//
+// target[i][j][l] = sum_r u_r[i] v_r[j] w_r[l]   (reference utils.py:218-232, datasets.py:127-141)
+//
+// is the one dense contraction on the path: per game a (32 x R) by (R x S^2) integer product,
+//     D[l][(i,j)] = sum_r  W[l][r] * P[r][(i,j)],      P[r][(i,j)] = u_r[i] * v_r[j],
+// with R ops per output byte (R = 64 at BASELINE config 5) -- compute-bound on the vector ALU
+// (tg_rows.h: 117 us for 4096 games at S = 25, R = 64, 44 % of the v_pk_mad_i16 rate), a small
+// fraction of the int8 MFMA rate.  One workgroup per game:
+//   1. the game's R x 3S factors (token - shift) are written to LDS TRANSPOSED, T[x][r], so that
+//      the 16 consecutive r a lane needs are one ds_read_b128;
+//   2. a wavefront owns column tiles of 32 columns n = (i,j).  Per 32 values of r: the A fragment is
+//      W (row l = lane & 31), the B fragment is built by the lane for its column: 16 byte products
+//      u_r[i] * v_r[j] (v_mul_i32_i24 with SDWA byte selects, written straight into the bytes of the
+//      fragment), then one v_mfma_i32_32x32x32_i8.  Products must fit int8: |u|, |v| <= 11
+//      (checked while staging; a game beyond that is done by slow_game).  Sums are int32: exact.
+//   3. "left int8" is a running max / min over the int32 results (v_max3 / v_min3); the low bytes of
+//      four results (four consecutive l) go as one dword -- unaligned for odd S, which gfx950's
+//      LDS takes -- into a dense S^3 image in LDS;
+//   4. the image goes out as aligned 16-byte chunks.
+// Built with -mllvm -amdgpu-mfma-vgpr-form: the results land in VGPRs, no v_accvgpr moves.
+// A and B fragments use the same lane -> r mapping, so the result does not depend on how the
+// instruction orders k inside a fragment; C/D is the 32x32 map of the guide (col = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
+#pragma once
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+template <int S>
+struct MGeo {
+  static constexpr int N = S * S * S, S2 = S * S, A3 = 3 * S;
+  static constexpr int NT = (S2 + 31) / 32;   // column tiles per game
+  static constexpr int TROWS = 2 * S + 32;    // rows of T: u (S), v (S), w padded to 32
+  static constexpr int NCHUNK = (N + 15) / 16;
+  static constexpr int TAIL = N % 16;
+  static constexpr int IMG = NCHUNK * 16;     // bytes of the output image
+  static constexpr int UVLIM = 11;            // |u|, |v| <= 11: u * v fits int8
+};
+
+// bytes of dynamic LDS for R actions padded to Rp (a multiple of 32)
+template <int S>
+constexpr int mfma_lds_bytes(int Rp) { return MGeo<S>::TROWS * (Rp + 16) + MGeo<S>::IMG + 32; }
+
+// 16 byte-wise products a[k] * b[k] (signed) -> bytes of the result.  The four dwords are
+// independent chains interleaved so that an instruction never reads the register the previous one
+// wrote with a byte dst_sel; the closing s_nop covers "VALU write -> MFMA operand".
+__device__ __forceinline__ v4i bytemul16(const v4i a, const v4i b) {
+  v4i d;
+#define TG_BM(D, A, B, SEL, KEEP)                                                                     \
+  "v_mul_i32_i24_sdwa " D ", sext(" A "), sext(" B ") dst_sel:" SEL " dst_unused:" KEEP " src0_sel:" SEL \
+  " src1_sel:" SEL "\n\t"
+  asm(TG_BM("%0", "%4", "%8", "BYTE_0", "UNUSED_PAD") TG_BM("%1", "%5", "%9", "BYTE_0", "UNUSED_PAD")
+      TG_BM("%2", "%6", "%10", "BYTE_0", "UNUSED_PAD") TG_BM("%3", "%7", "%11", "BYTE_0", "UNUSED_PAD")
+      TG_BM("%0", "%4", "%8", "BYTE_1", "UNUSED_PRESERVE") TG_BM("%1", "%5", "%9", "BYTE_1", "UNUSED_PRESERVE")
+      TG_BM("%2", "%6", "%10", "BYTE_1", "UNUSED_PRESERVE") TG_BM("%3", "%7", "%11", "BYTE_1", "UNUSED_PRESERVE")
+      TG_BM("%0", "%4", "%8", "BYTE_2", "UNUSED_PRESERVE") TG_BM("%1", "%5", "%9", "BYTE_2", "UNUSED_PRESERVE")
+      TG_BM("%2", "%6", "%10", "BYTE_2", "UNUSED_PRESERVE") TG_BM("%3", "%7", "%11", "BYTE_2", "UNUSED_PRESERVE")
+      TG_BM("%0", "%4", "%8", "BYTE_3", "UNUSED_PRESERVE") TG_BM("%1", "%5", "%9", "BYTE_3", "UNUSED_PRESERVE")
+      TG_BM("%2", "%6", "%10", "BYTE_3", "UNUSED_PRESERVE") TG_BM("%3", "%7", "%11", "BYTE_3", "UNUSED_PRESERVE")
+      "s_nop 1"
+      : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
+      : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+#undef TG_BM
+  return d;
+}
+
+struct __attribute__((packed)) UnalignedU32 { uint32_t v; };  // gfx950 LDS takes unaligned dwords (ds_write_b32)
+
+// KS: k-steps of 32 actions known at compile time (1 or 2: R <= 64), 0 = run-time Rp / 32.
+template <int S, int KS>
+__global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) {
+  using G = MGeo<S>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t mfma_smem[];
+  if constexpr (KS != 0) Rp = 32 * KS;
+  const int RS = Rp + 16;  // row stride of T: a multiple of 16 (ds_read_b128), 5 bank quads apart at Rp = 64
+  int8_t* const T = reinterpret_cast<int8_t*>(mfma_smem);
+  uint8_t* const img = mfma_smem + G::TROWS * RS;
+  uint8_t* const flags = img + G::IMG + 16;  // the last column's closing dword may spill <= 3 bytes past N
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int R = a.nact;
+
+  // rows l >= S of W never receive a factor: zero them once, so that the unused rows of D are zero
+  for (int e = tid; e < (32 - S) * RS; e += kBlock) T[(3 * S) * RS + e] = 0;
+
+  // staging role: lane = (token position x, one of NRG groups of actions); each trip handles 4 actions
+  constexpr int NRG = kBlock / G::A3;
+  constexpr int TB = 6;  // trips per batch: every byte load of a batch is in flight before one is used
+  const int sx = tid % G::A3, srg = tid / G::A3;
+  const int slo = sx < 2 * S ? -G::UVLIM : -128, shi = sx < 2 * S ? G::UVLIM : 127;
+
+  // tile role: this wavefront's column tiles are the same for every game
+  constexpr int NW = kBlock / 64, TPW = (G::NT + NW - 1) / NW;
+  int uoff[TPW], voff[TPW], ncol[TPW];
+#pragma unroll
+  for (int k = 0; k < TPW; ++k) {
+    const int n = 32 * (wave + NW * k) + col;
+    const int nn = n < G::S2 ? n : G::S2 - 1;  // columns past S^2 shadow the last one; never stored
+    const int i = nn / S, j = nn - i * S;
+    uoff[k] = i * RS + 16 * h;
+    voff[k] = (S + j) * RS + 16 * h;
+    ncol[k] = n < G::S2 ? n : -1;
+  }
+  const int woff = (2 * S + col) * RS + 16 * h;
+
+  for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
+    // ---- 1. factors of this game, transposed into LDS (4 actions = one dword); range check; r >= R -> 0 ----
+    const int8_t* tok = a.actions + g * R * G::A3;  // uniform; lane offsets are 32-bit
+    int big = 0;
+    if (srg < NRG) {
+      for (int rb = 4 * srg; rb < Rp; rb += 4 * NRG * TB) {
+        int f[TB][4];
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int r = rb + 4 * NRG * tb + t;
+            f[tb][t] = tok[sx + min(r, R - 1) * G::A3];
+          }
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+          const int r0 = rb + 4 * NRG * tb;
+          if (r0 < Rp) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              f[tb][t] = (r0 + t < R) ? f[tb][t] - a.shift : 0;
+              big |= (f[tb][t] < slo) | (f[tb][t] > shi);
+            }
+            *reinterpret_cast<uint32_t*>(T + sx * RS + r0) = pack4(f[tb][0], f[tb][1], f[tb][2], f[tb][3]);
+          }
+        }
+      }
+    }
+    if (__syncthreads_or(big)) {  // workgroup-uniform; rare: exact byte-wise form
+      note_fallback();
+      slow_game<GENF>(a, g, flags);
+      __syncthreads();
+      continue;
+    }
+
+    // ---- 2. column tiles on the matrix cores, two at a time ----
+    int hi = 0, lo = 0;  // running max / min of every result of this lane
+    v4i wa[KS ? KS : 1];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) wa[k] = *reinterpret_cast<const v4i*>(T + woff + 32 * k);
+    // one tile -> X[q] = the low bytes of this lane's results for rows l = 8 q + 4 h + (0..3)
+    auto tile = [&](int k, uint32_t (&X)[4]) {
+      v16i acc;
+#pragma unroll
+      for (int t2 = 0; t2 < 16; ++t2) acc[t2] = 0;
+      if constexpr (KS != 0) {
+        v4i p[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          p[ks] = bytemul16(*reinterpret_cast<const v4i*>(T + uoff[k] + 32 * ks),
+                            *reinterpret_cast<const v4i*>(T + voff[k] + 32 * ks));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa[ks], p[ks], acc, 0, 0, 0);
+      } else {
+        for (int k0 = 0; k0 < Rp; k0 += 32) {
+          const v4i w = *reinterpret_cast<const v4i*>(T + woff + k0);
+          const v4i p = bytemul16(*reinterpret_cast<const v4i*>(T + uoff[k] + k0),
+                                  *reinterpret_cast<const v4i*>(T + voff[k] + k0));
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, p, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < 16; t2 += 2) {
+        hi = max(max(acc[t2], acc[t2 + 1]), hi);
+        lo = min(min(acc[t2], acc[t2 + 1]), lo);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) X[q] = pack4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+      asm volatile("" : "+v"(hi), "+v"(lo), "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]));  // one tile live at a time
+    };
+#pragma unroll
+    for (int k = 0; k < TPW; k += 2) {
+      if (G::NT % NW != 0 && wave + NW * k >= G::NT) break;  // wave-uniform
+      __builtin_amdgcn_sched_barrier(0);
+      uint32_t XA[4], XB[4] = {0, 0, 0, 0};
+      tile(k, XA);
+      const bool pair = k + 1 < TPW && (G::NT % NW == 0 || wave + NW * (k + 1) < G::NT);  // wave-uniform
+      if (pair) tile(k + 1, XB);
+      // Lane (col, h) of tile A holds rows 8q+4h+(0..3) of column col; its partner lane (col, 1-h) holds the
+      // others.  v_permlane32_swap exchanges XA of the upper half-wave with XB of the lower one: afterwards the
+      // LOWER half-wave owns whole columns of tile A, the UPPER half-wave whole columns of tile B:
+      // U[q] = rows 8q..8q+3, V[q] = rows 8q+4..8q+7 of the lane's column.
+      uint32_t E[9];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(XA[q], XB[q], false, false);
+        E[2 * q] = sw[0];
+        E[2 * q + 1] = sw[1];
+      }
+      E[8] = 0;
+      const int nown = h ? (pair ? ncol[k + 1 < TPW ? k + 1 : k] : -1) : ncol[k];
+      // The column is S bytes at image offset S*n: not dword aligned for odd S, and gfx950's LDS stalls on
+      // unaligned dwords (SQ_LDS_UNALIGNED_STALL was half of the kernel).  So every lane writes the ALIGNED
+      // dwords that START inside its column; the last of them is completed with the first bytes of the next
+      // column, fetched from the next lane (a tile's 32 columns are 32 S bytes: 16-byte aligned at both ends).
+      constexpr int Q = (S + 3) / 4, r = S % 4;
+      static_assert(r <= 1, "tg_mfma.h: column emission handles S % 4 in {0, 1}");
+      if constexpr (r == 1) {
+        const uint32_t nxt = __builtin_amdgcn_update_dpp(0u, E[0], 0x130, 0xf, 0xf, false);  // lane + 1's first dword
+        E[Q - 1] |= nxt << 8;  // rows >= S of D are zero (the W rows there are), so the upper bytes were 0
+      }
+      if (nown >= 0) {
+        const int base = nown * S;
+        const int o = (4 - (base & 3)) & 3;  // first aligned dword starting inside the column
+        uint8_t* dst = img + base + o;
+#pragma unroll
+        for (int jd = 0; jd < Q; ++jd) {
+          if (4 * jd + o < S) {  // o == 0 for every lane when S % 4 == 0
+            const uint32_t d = __builtin_amdgcn_alignbyte(E[jd + 1], E[jd], static_cast<uint32_t>(o));
+            *reinterpret_cast<uint32_t*>(dst + 4 * jd) = d;
+          }
+        }
+      }
+    }
+    const bool any_ovf = __syncthreads_or((hi > 127) | (lo < -128));  // also: the image is complete
+
+    // ---- 3. image -> global, 16-byte chunks ----
+    int8_t* out = a.out + g * a.out_stride;
+    for (int c = tid; c < G::NCHUNK; c += kBlock)
+      store_chunk<G::TAIL>(out + 16 * c, *reinterpret_cast<const uint4*>(img + 16 * c), c == G::NCHUNK - 1);
+    if (tid == 0 && any_ovf && a.overflow) a.overflow[g] = 1;
+    __syncthreads();  // T and the image are reused by the next game
+  }
+}
