@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/tensor_game.h"
 #include "tg_device.h"
@@ -194,6 +195,102 @@ __global__ __launch_bounds__(192) void basis_tokens_kernel(int8_t* actions, uint
   }
 }
 
+// The same change of basis on the matrix cores (S = 9, 16, 25).  For one game, mode x and 32 actions
+//     D[a][r] = sum_i M_x[a][i] * t_r[i]          (t = raw token bytes, i < S; 32x32x32 int8 MFMA)
+//     token'_r[a] = D[a][r] - shift * rowsum(M_x[a]) + shift
+// The A fragment is a row of M_x, the B fragment a row of the token block: both are 16 contiguous
+// bytes per lane, read straight from global memory (unaligned dwords, nothing past the S valid bytes
+// of a row is touched; bytes i >= S of both fragments are zero, so padding never contributes).  The
+// result has the action on the lane and four consecutive a per register group: one dword store.
+// A job reads only the bytes it later writes, so the transform is in place.  Exact: int32 sums; tokens
+// that leave int8 wrap and raise the game's overflow flag, as in basis_tokens_kernel.
+typedef int bt_v4i __attribute__((ext_vector_type(4)));
+typedef int bt_v16i __attribute__((ext_vector_type(16)));
+
+template <int S>
+__device__ __forceinline__ bt_v4i load_row_fragment(const int8_t* row, int h) {  // bytes 16h..16h+15 of an S-byte row
+  bt_v4i f;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    uint32_t w = 0;
+    const int k0 = 16 * h + 4 * d;
+    if (k0 + 3 < S) {
+      __builtin_memcpy(&w, row + k0, 4);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (k0 + t < S) w |= static_cast<uint32_t>(static_cast<uint8_t>(row[k0 + t])) << (8 * t);
+    }
+    f[d] = static_cast<int>(w);
+  }
+  return f;
+}
+
+template <int S>
+__global__ __launch_bounds__(kBlock) void basis_tokens_mfma_kernel(int8_t* actions, uint8_t* overflow, int64_t B, int R,
+                                                                   int shift, const int8_t* basis) {
+  __shared__ __attribute__((aligned(16))) int rowsum[kBlock / 64][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int ntile = (R + 31) >> 5, njob = 3 * ntile;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    int8_t* blk = actions + b * R * 3 * S;
+    int hi = 0, lo = 0;
+    for (int job = wave; job < njob; job += kBlock / 64) {
+      const int x = job / ntile, r0 = 32 * (job - x * ntile);
+      // A: row a = col of M_x (rows >= S shadow the last one; their results are never used)
+      const int8_t* mrow = basis + ((b * 3 + x) * S + (col < S ? col : S - 1)) * S;
+      const bt_v4i fa = load_row_fragment<S>(mrow, h);
+      // B: action r0 + col (actions >= R shadow the last one; never stored)
+      const int r = r0 + col;
+      int8_t* trow = blk + static_cast<int64_t>(r < R ? r : R - 1) * 3 * S + x * S;
+      const bt_v4i fb = load_row_fragment<S>(trow, h);
+      // row sums of M_x for the shift correction: this lane has half a row, its partner lane the other half
+      int part = 0;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) part = __builtin_amdgcn_sdot4(fa[d], 0x01010101, part, false);
+      part += __shfl_xor(part, 32);
+      if (h == 0) rowsum[wave][col] = part;
+      bt_v16i acc;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[t] = 0;
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int a0 = 8 * q + 4 * h;  // this lane's rows of D in register group q
+        const bt_v4i rs = *reinterpret_cast<const bt_v4i*>(&rowsum[wave][a0]);
+        int tokv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          tokv[t] = acc[4 * q + t] - shift * rs[t] + shift;
+          if (8 * q + t + 4 < S) {  // valid for both halves
+            hi = max(hi, tokv[t]);
+            lo = min(lo, tokv[t]);
+          } else if (8 * q + t < S) {
+            if (a0 + t < S) {
+              hi = max(hi, tokv[t]);
+              lo = min(lo, tokv[t]);
+            }
+          }
+        }
+        if (r < R) {
+          int8_t* dst = trow + a0;
+          if (8 * q + 8 <= S) {
+            const uint32_t w = pack4(tokv[0], tokv[1], tokv[2], tokv[3]);
+            __builtin_memcpy(dst, &w, 4);
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (8 * q + t < S && a0 + t < S) dst[t] = static_cast<int8_t>(tokv[t]);
+          }
+        }
+      }
+    }
+    const bool bad = __syncthreads_or((hi > 127) | (lo < -128));
+    if (threadIdx.x == 0 && overflow && bad) overflow[b] = 1;
+  }
+}
+
 // One workgroup per (game, mode): L and U cells from one draw each, then P = L @ U.
 __global__ __launch_bounds__(kBlock) void sample_basis_kernel(int8_t* P, int8_t* Lo, int8_t* Uo, int64_t B, int S,
                                                               Dist D, uint64_t seed, uint64_t gid0) {
@@ -365,11 +462,16 @@ int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, 
   if (basis) {
     const size_t lds = 3 * static_cast<size_t>(S) * S * sizeof(int) + 64 * 3 * static_cast<size_t>(S);
     const dim3 bgrid(grid_for(B > 16384 ? 16384 : B)), bblock(192);
-    switch (S) {
+    static const bool no_mfma = getenv("TG_NO_MFMA") != nullptr;  // A/B switch for measurements
+    const dim3 mgrid(grid_for(B > 65536 ? 65536 : B)), mblock(tg::kBlock);
+    switch (no_mfma ? -S : S) {
+      case 9: hipLaunchKernelGGL(tg::basis_tokens_mfma_kernel<9>, mgrid, mblock, 0, st, actions_out, overflow, B, R, shift, basis); break;
+      case 16: hipLaunchKernelGGL(tg::basis_tokens_mfma_kernel<16>, mgrid, mblock, 0, st, actions_out, overflow, B, R, shift, basis); break;
+      case 25: hipLaunchKernelGGL(tg::basis_tokens_mfma_kernel<25>, mgrid, mblock, 0, st, actions_out, overflow, B, R, shift, basis); break;
       case 4: hipLaunchKernelGGL(tg::basis_tokens_kernel<4>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
-      case 9: hipLaunchKernelGGL(tg::basis_tokens_kernel<9>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
-      case 16: hipLaunchKernelGGL(tg::basis_tokens_kernel<16>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
-      case 25: hipLaunchKernelGGL(tg::basis_tokens_kernel<25>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
+      case -9: hipLaunchKernelGGL(tg::basis_tokens_kernel<9>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
+      case -16: hipLaunchKernelGGL(tg::basis_tokens_kernel<16>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
+      case -25: hipLaunchKernelGGL(tg::basis_tokens_kernel<25>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
       default: hipLaunchKernelGGL(tg::basis_tokens_kernel<0>, bgrid, bblock, lds, st, actions_out, overflow, B, S, R, shift, basis); break;
     }
   }

@@ -890,6 +890,18 @@ int validate_common(const char* fn, int64_t B, int S, int64_t stride) {
   return TG_OK;
 }
 
+int device_cu_count() {  // of the current device; 256 on MI355X
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cached[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 unsigned capped_grid(int64_t blocks) {
   const int64_t cap = 1 << 20;
   return static_cast<unsigned>(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
@@ -951,24 +963,37 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
     // the accumulation over R is a dense contraction: matrix cores (tg_mfma.h); u*v must fit int8 (checked
     // on device, per game), the transposed factors of one game must fit LDS
     if (aligned16(a.out) && a.out_stride % 16 == 0 && a.nact <= 256 && !force_i32 && !no_mfma) {
+#define TG_MFMA_K(S_, KS_)                                                                      \
+  do {                                                                                           \
+    /* a workgroup's set-up (tile offsets, staging addresses) is a third of one game's work: give every */ \
+    /* workgroup several games, as many workgroups as the chip holds at once, games split evenly */ \
+    static int occ_lds = -1, occ_val = 1;  /* per instantiation; a stale value only changes the grid shape */ \
+    if (occ_lds != ldsb) {                                                                       \
+      int v = 0;                                                                                 \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, genf_mfma_kernel<S_, KS_>, kBlock, ldsb) != hipSuccess || v < 1) v = 1; \
+      occ_val = v;                                                                               \
+      occ_lds = ldsb;                                                                            \
+    }                                                                                            \
+    const int per_cu = occ_val;                                                                  \
+    const int64_t resident = static_cast<int64_t>(per_cu) * device_cu_count();                   \
+    const int64_t per_wg = (B + resident - 1) / resident;                                        \
+    const int64_t grid = (B + per_wg - 1) / per_wg;                                              \
+    (void)hipGetLastError();                                                                     \
+    hipLaunchKernelGGL((genf_mfma_kernel<S_, KS_>), dim3((unsigned)grid), dim3(kBlock), ldsb, st, a, Rp); \
+    return check_launch(fn);                                                                     \
+  } while (0)
 #define TG_MFMA(S_)                                                                              \
   do {                                                                                           \
     const int Rp = (a.nact + 31) & ~31;                                                          \
-    (void)hipGetLastError();                                                                     \
-    if (Rp == 32)                                                                                \
-      hipLaunchKernelGGL((genf_mfma_kernel<S_, 1>), dim3(capped_grid(B)), dim3(kBlock),          \
-                         mfma_lds_bytes<S_>(Rp), st, a, Rp);                                     \
-    else if (Rp == 64)                                                                           \
-      hipLaunchKernelGGL((genf_mfma_kernel<S_, 2>), dim3(capped_grid(B)), dim3(kBlock),          \
-                         mfma_lds_bytes<S_>(Rp), st, a, Rp);                                     \
-    else                                                                                         \
-      hipLaunchKernelGGL((genf_mfma_kernel<S_, 0>), dim3(capped_grid(B)), dim3(kBlock),          \
-                         mfma_lds_bytes<S_>(Rp), st, a, Rp);                                     \
-    return check_launch(fn);                                                                     \
+    const int ldsb = mfma_lds_bytes<S_>(Rp);                                                     \
+    if (Rp == 32) TG_MFMA_K(S_, 1);                                                              \
+    if (Rp == 64) TG_MFMA_K(S_, 2);                                                              \
+    TG_MFMA_K(S_, 0);                                                                            \
   } while (0)
       if (a.S == 9) TG_MFMA(9);
       if (a.S == 16) TG_MFMA(16);
       if (a.S == 25) TG_MFMA(25);
+#undef TG_MFMA_K
 #undef TG_MFMA
     }
   }
