@@ -219,6 +219,54 @@ def test_step_extreme_factors_full_int8_range(S):
             assert not want_ovf[0::4].any() and want_ovf.any()
 
 
+@pytest.mark.parametrize("S", [9, 16, 25])
+@pytest.mark.parametrize("R", [1, 31, 32, 33, 64, 65, 100, 256, 257])
+def test_gen_from_factors_matrix_core_path(S, R):
+    """tg_mfma.h: R around the 32-action k-steps (compile-time 1 and 2 steps, run-time loop, the
+    R > 256 hand-over to the vector kernels), factors at and beyond the |u|,|v| <= 11 bound of the
+    int8 byte products (games beyond it take the exact byte-wise form), full-range w, overflow."""
+    rng = np.random.default_rng(1000 * S + R)
+    B = 13
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, R, 3 * S)).astype(np.int8)
+    ac[1] = rng.integers(-10, 13, size=(R, 3 * S))          # |u|,|v|,|w| <= 11 exactly at the bound
+    ac[2] = ac[1]
+    ac[2, R // 2, 3] = 13                                    # one u = 12: this game leaves the fast path
+    ac[3, :, 2 * S:] = rng.integers(-127, 128, size=(R, S))  # w = token - 1 down to -128: the whole int8 range
+    ac[4, :, :2 * S] = rng.integers(-10, 13, size=(R, 2 * S))
+    ac[5] = 1                                                # all-zero factors
+    ac[6, :, :] = rng.choice([0, 2], size=(R, 3 * S))        # +-1 only: sums up to R
+    want, wovf = O.gen_from_factors_i8(ac, 1)
+    ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    before = ops.debug_fallbacks()
+    out = ops.gen_from_factors(dev(ac), S, overflow=ovf)
+    assert np.array_equal(host(out), want) and np.array_equal(host(ovf), wovf)
+    if R <= 256:
+        assert ops.debug_fallbacks() - before == 1           # game 2 only
+    # padded game stride and a second shift
+    want2, wovf2 = O.gen_from_factors_i8(ac, 2)
+    buf = ops.alloc_states(B, S, DEV)
+    ovf.zero_()
+    ops.gen_from_factors(dev(ac), S, out=buf, overflow=ovf, shift=2)
+    assert np.array_equal(host(buf), want2) and np.array_equal(host(ovf), wovf2)
+
+
+@pytest.mark.parametrize("S,R", [(9, 5), (16, 33), (25, 64), (25, 70)])
+def test_basis_tokens_matrix_core_path_large_entries(S, R):
+    """Change of basis on the tokens with basis entries over the whole int8 range (not unimodular: the
+    kernel does not care) and shift 2: wrapped tokens + overflow flag must equal the oracle's."""
+    rng = np.random.default_rng(77 * S + R)
+    B = 9
+    P = rng.integers(-3, 4, size=(B, 3, S, S)).astype(np.int8)
+    P[0] = rng.integers(-128, 128, size=(3, S, S))
+    P[1] = np.eye(S, dtype=np.int8)
+    thr = O.categorical_thresholds((0.15, 0.7, 0.15))
+    tok_o, tgt_o, ovf_o = O.gen_demos_i8(B, S, R, thr, (-1, 0, 1), 2, seed=5, basis=P)
+    ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    tok, tgt = ops.gen_demos(B, S, R, DEV, seed=5, shift=2, basis=dev(P), overflow=ovf)
+    assert np.array_equal(host(tok), tok_o) and np.array_equal(host(tgt), tgt_o)
+    assert np.array_equal(host(ovf), ovf_o) and ovf_o[0] == 1 and ovf_o[1] == 0
+
+
 @pytest.mark.parametrize("S,B,K", [(4, 130, 7), (4, 5, 40), (9, 33, 12), (16, 9, 70), (25, 3, 130), (5, 6, 9), (2, 3, 3)])
 def test_step_many_matches_oracle(S, B, K):
     rng = np.random.default_rng(S * 31 + K)
@@ -618,11 +666,18 @@ for S, B, K in [(9, 9, 6), (16, 6, 5), (25, 3, 7)]:
     k, dn, ch = ops.expand(t, a)
     assert np.array_equal(k.cpu().numpy(), wk) and np.array_equal(dn.cpu().numpy(), wdn) and np.array_equal(ch.cpu().numpy(), wch)
     assert np.array_equal(ops.gen_from_factors(a, S).cpu().numpy(), O.gen_from_factors_i8(ac)[0])
+    thr = O.categorical_thresholds((0.15, 0.7, 0.15))
+    P_o, _, _ = O.sample_basis(B, S, O.categorical_thresholds((0.05, 0.9, 0.05)), (-1, 0, 1), seed=4)
+    tok_o, tgt_o, ovf_o = O.gen_demos_i8(B, S, 40, thr, (-1, 0, 1), 1, seed=3, basis=P_o)
+    ovf = torch.zeros(B, dtype=torch.uint8, device="cuda:0")
+    tok, tgt = ops.gen_demos(B, S, 40, "cuda:0", seed=3, basis=torch.from_numpy(P_o.astype(np.int8)).cuda(), overflow=ovf)
+    assert np.array_equal(tok.cpu().numpy(), tok_o) and np.array_equal(tgt.cpu().numpy(), tgt_o)
+    assert np.array_equal(ovf.cpu().numpy(), ovf_o)
 print("AB_OK")
 '''
 
 
-@pytest.mark.parametrize("env_name", ["TG_FORCE_I32", "TG_NO_ROWS", "TG_NO_S16_DIRECT"])
+@pytest.mark.parametrize("env_name", ["TG_FORCE_I32", "TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA"])
 def test_ab_switch_paths_stay_exact(env_name, tmp_path):
     """The measurement switches (32-bit cursor kernels; packed chunks instead of rows) select
     kernels that the default dispatch no longer uses -- they must stay bit-exact too."""
