@@ -331,6 +331,41 @@ def main():
                              "ok": bool(((ds >= 0) & (ds < k2)).all()) and not bool(st2.any()),
                              "value": round(b2 * k2 / sec, 1), "unit": "steps/s",
                              "us_per_launch": round(sec * 1e6, 2), "GBps": round(nbytes / sec / 1e9, 1)})
+            # BASELINE config 5's generator (per-GPU share: 4 096 demos, S=25, R=64), with and without the change
+            # of basis; bytes = tokens written and re-read + target written; replayed as a hipGraph
+            for with_basis in (False, True):
+                s2, b2, r2 = 25, 4096, 64
+                P = ops.sample_basis(b2, s2, dev, seed=11) if with_basis else None
+                tok = torch.empty((b2, r2, 3 * s2), dtype=torch.int8, device=dev)
+                tgt = ops.alloc_states(b2, s2, dev)
+                ovf = torch.zeros(b2, dtype=torch.uint8, device=dev)
+                for _ in range(3):
+                    ops.gen_demos(b2, s2, r2, dev, seed=7, basis=P, target=tgt, actions=tok, overflow=ovf)
+                reps = 20
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                gg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gg, stream=side):
+                    for _ in range(reps):
+                        ops.gen_demos(b2, s2, r2, dev, seed=7, basis=P, target=tgt, actions=tok, overflow=ovf)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                gg.replay()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                gg.replay()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                sec = e0.elapsed_time(e1) * 1e-3 / reps
+                # self-check: replaying the demo's own actions must bring every target to zero
+                _, dstep = ops.step_many(tgt, tok)
+                nbytes = b2 * (s2 ** 3 + 2 * 3 * s2 * r2)
+                also.append({"workload": f"GENERATOR tg_gen_demos_i8: S={s2} R={r2}, {b2} demos per launch"
+                                         f"{' in a random GL(S,Z) basis' if with_basis else ''} (BASELINE config 5 per GPU)",
+                             "ok": bool((dstep >= 0).all()) and (with_basis or not bool(ovf.any())),
+                             "value": round(b2 / sec, 1), "unit": "demos/s", "us_per_launch": round(sec * 1e6, 2),
+                             "GBps": round(nbytes / sec / 1e9, 1), "hbm_frac": round(nbytes / sec / 1e9 / 8000.0, 4),
+                             "TMACps": round(b2 * r2 * s2 ** 3 / sec / 1e12, 2)})
             out["also"] = also
             # BASELINE's metric names S=4 and S=16: surface config 3 at the top level as well
             for a3 in also:
