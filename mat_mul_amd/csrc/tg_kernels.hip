@@ -986,8 +986,9 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
   do {                                                                                           \
     const int Rp = (a.nact + 31) & ~31;                                                          \
     const int ldsb = mfma_lds_bytes<S_>(Rp);                                                     \
-    if (Rp == 32) TG_MFMA_K(S_, 1);                                                              \
-    if (Rp == 64) TG_MFMA_K(S_, 2);                                                              \
+    static const bool ks0 = getenv("TG_MFMA_KS0") != nullptr;                                    \
+    if (Rp == 32 && !ks0) TG_MFMA_K(S_, 1);                                                      \
+    if (Rp == 64 && !ks0) TG_MFMA_K(S_, 2);                                                      \
     TG_MFMA_K(S_, 0);                                                                            \
   } while (0)
       if (a.S == 9) TG_MFMA(9);

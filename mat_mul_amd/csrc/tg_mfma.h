@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) 
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int r = rb + 4 * NRG * tb + t;
-            f[tb][t] = tok[sx + min(r, R - 1) * G::A3];
+            f[tb][t] = tok[static_cast<uint32_t>(sx + min(r, R - 1) * G::A3)];  // unsigned: SGPR base + 32-bit lane offset
           }
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb) {
