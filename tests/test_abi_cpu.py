@@ -98,3 +98,18 @@ def test_product_never_imports_oracle():
     for f in (ROOT / "mat_mul_amd").glob("*.py"):
         src = f.read_text()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_header_is_plain_c():
+    """The drop-in boundary is a C ABI: include/tensor_game.h must compile as C99 (no C++, no torch,
+    no HIP headers), so any FFI (cgo, JNI, ctypes, cffi) can consume it."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    hdr = Path(__file__).resolve().parent.parent / "include" / "tensor_game.h"
+    res = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Wpedantic", "-Werror", str(hdr)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
