@@ -452,6 +452,52 @@ __device__ __forceinline__ void s4_rank1(int (&acc)[16], const S4Factors& f, int
   }
 }
 
+// One step on one 16-byte slice (S = 4, lane q owns slice i = q), the body of tg_step_i8 and of the
+// child-per-team tg_expand_i8.  Packed form: the slice as 8 sign-extended int16 pairs, 8 saturating
+// v_pk_mad_i16.  No range check on the factors is needed: with |factor| <= 255 (int8 token,
+// |shift| <= 127, else the 32-bit form) u*v is formed exactly and SATURATES beyond int16, and so does
+// (u v) w + x, so every case the 16-bit form cannot represent ends outside [-128, 127] -- exactly the
+// cases where the true result overflows int8 (|x| <= 128 cannot bring a saturated product back).
+// Those lanes redo their slice in 32-bit (wrapped bytes + flag, as the contract wants); all others
+// are exact.  ~55 VALU ops per lane instead of ~105: at cfg2 the four wavefronts of a SIMD all get
+// their data at the same time, so the arithmetic is on the launch's critical path.
+// nz |= result bytes; ovf |= (n + 128) of the 32-bit form only (test ovf & ~255).
+__device__ __forceinline__ uint4 s4_step_slice(const uint4 in_slice, uint32_t du, uint32_t dv, uint32_t dw, int q,
+                                               int shift, uint32_t& nz, int& ovf) {
+  const uint32_t shp = (static_cast<uint32_t>(shift) & 0xFFFFu) | (static_cast<uint32_t>(shift) << 16);
+  const int ui = shift - __builtin_amdgcn_sbfe(static_cast<int>(du), 8 * q, 8);  // -(u_i)
+  const uint32_t uip = __builtin_amdgcn_perm(static_cast<uint32_t>(ui), static_cast<uint32_t>(ui), 0x05040100u);
+  const uint32_t yv = dv << 8, yw = dw << 8;
+  const uint32_t vA = pk_sub_i16(__builtin_amdgcn_perm(dv, yv, 0x0A050804u), shp);  // (v0, v1)
+  const uint32_t vB = pk_sub_i16(__builtin_amdgcn_perm(dv, yv, 0x0B070906u), shp);  // (v2, v3)
+  const uint32_t wA = pk_sub_i16(__builtin_amdgcn_perm(dw, yw, 0x0A050804u), shp);  // (w0, w1)
+  const uint32_t wB = pk_sub_i16(__builtin_amdgcn_perm(dw, yw, 0x0B070906u), shp);  // (w2, w3)
+  const uint32_t uvA = pk_mad_i16_sat(vA, uip, 0u), uvB = pk_mad_i16_sat(vB, uip, 0u);
+  uint32_t A[8];
+  unpack_pairs(in_slice, A);
+  A[0] = pk_mad_i16_sat_lo(uvA, wA, A[0]);  // row j = 0: -u v0 in both halves
+  A[1] = pk_mad_i16_sat_lo(uvA, wB, A[1]);
+  A[2] = pk_mad_i16_sat_hi(uvA, wA, A[2]);  // j = 1
+  A[3] = pk_mad_i16_sat_hi(uvA, wB, A[3]);
+  A[4] = pk_mad_i16_sat_lo(uvB, wA, A[4]);  // j = 2
+  A[5] = pk_mad_i16_sat_lo(uvB, wB, A[5]);
+  A[6] = pk_mad_i16_sat_hi(uvB, wA, A[6]);  // j = 3
+  A[7] = pk_mad_i16_sat_hi(uvB, wB, A[7]);
+  uint32_t ovf16 = 0;
+  uint4 pk = pack_pairs(A, nz, ovf16);
+  const bool wide_shift = static_cast<unsigned>(shift + 127) > 254u;  // uniform; factors may exceed 255
+  if (__builtin_expect(wide_shift || (ovf16 & 0xFF00FF00u), 0)) {  // rare, per lane: exact 32-bit form of this slice
+    const int cur[3] = {static_cast<int>(du), static_cast<int>(dv), static_cast<int>(dw)};
+    const S4Factors f = s4_factors<true>(cur, q, shift);
+    int acc[16], chg = 0;
+    nz = 0;
+    unpack16(in_slice, acc);
+    s4_rank1(acc, f, chg);
+    pk = pack16(acc, nz, ovf);
+  }
+  return pk;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
   // Addressing: everything that depends on blockIdx is SCALAR 64-bit math (SALU); the per-lane
@@ -475,46 +521,9 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
     int8_t* out_blk = a.out + g0 * a.out_stride;
     const uint32_t out_off = __umul24(lg, static_cast<uint32_t>(a.out_stride)) + 16u * q;
     if constexpr (MODE == STEP || MODE == STEPS) {
-      // Packed form: the slice as 8 sign-extended int16 pairs, 8 saturating v_pk_mad_i16.  No range
-      // check on the factors is needed: with |factor| <= 255 (int8 token, |shift| <= 127, else the
-      // 32-bit form below) u*v is formed exactly and SATURATES beyond int16, and so does (u v) w + x, so every
-      // case the 16-bit form cannot represent ends outside [-128, 127] -- exactly the cases where the
-      // true result overflows int8 (|x| <= 128 cannot bring a saturated product back).  Those lanes
-      // redo their slice in 32-bit below (wrapped bytes + flag, as the contract wants); all others
-      // are exact.  ~55 VALU ops per lane instead of ~105: at cfg2 the four wavefronts of a SIMD
-      // all get their data at the same time, so the arithmetic is on the launch's critical path.
       const uint32_t du = tok[0], dv = tok[1], dw = tok[2];
-      const uint32_t shp = (static_cast<uint32_t>(a.shift) & 0xFFFFu) | (static_cast<uint32_t>(a.shift) << 16);
-      const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(du), 8 * q, 8);  // -(u_i)
-      const uint32_t uip = __builtin_amdgcn_perm(static_cast<uint32_t>(ui), static_cast<uint32_t>(ui), 0x05040100u);
-      const uint32_t yv = dv << 8, yw = dw << 8;
-      const uint32_t vA = pk_sub_i16(__builtin_amdgcn_perm(dv, yv, 0x0A050804u), shp);  // (v0, v1)
-      const uint32_t vB = pk_sub_i16(__builtin_amdgcn_perm(dv, yv, 0x0B070906u), shp);  // (v2, v3)
-      const uint32_t wA = pk_sub_i16(__builtin_amdgcn_perm(dw, yw, 0x0A050804u), shp);  // (w0, w1)
-      const uint32_t wB = pk_sub_i16(__builtin_amdgcn_perm(dw, yw, 0x0B070906u), shp);  // (w2, w3)
-      const uint32_t uvA = pk_mad_i16_sat(vA, uip, 0u), uvB = pk_mad_i16_sat(vB, uip, 0u);
-      uint32_t A[8];
-      unpack_pairs(pk, A);
-      A[0] = pk_mad_i16_sat_lo(uvA, wA, A[0]);  // row j = 0: -u v0 in both halves
-      A[1] = pk_mad_i16_sat_lo(uvA, wB, A[1]);
-      A[2] = pk_mad_i16_sat_hi(uvA, wA, A[2]);  // j = 1
-      A[3] = pk_mad_i16_sat_hi(uvA, wB, A[3]);
-      A[4] = pk_mad_i16_sat_lo(uvB, wA, A[4]);  // j = 2
-      A[5] = pk_mad_i16_sat_lo(uvB, wB, A[5]);
-      A[6] = pk_mad_i16_sat_hi(uvB, wA, A[6]);  // j = 3
-      A[7] = pk_mad_i16_sat_hi(uvB, wB, A[7]);
-      uint32_t nz = 0, ovf16 = 0;
-      const uint4 in_slice = pk;
-      pk = pack_pairs(A, nz, ovf16);
-      const bool wide_shift = static_cast<unsigned>(a.shift + 127) > 254u;  // uniform; factors may exceed 255
-      if (__builtin_expect(wide_shift || (ovf16 & 0xFF00FF00u), 0)) {  // rare, per lane: exact 32-bit form of this slice
-        const S4Factors f = s4_factors<true>(tok, q, a.shift);
-        int acc[16], chg = 0;
-        nz = 0;
-        unpack16(in_slice, acc);
-        s4_rank1(acc, f, chg);
-        pk = pack16(acc, nz, ovf);
-      }
+      uint32_t nz = 0;
+      pk = s4_step_slice(pk, du, dv, dw, q, a.shift, nz, ovf);
       // (skipping the store of untouched slices, as packed_kernel does in place, is SLOWER here: 16-byte
       // holes inside 64-byte games turn full-line writes into partial ones -- 2.83 -> 3.05 us at cfg2)
       if (live) *reinterpret_cast<uint4*>(out_blk + out_off) = pk;
@@ -695,6 +704,43 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
         if (a.overflow && any_ovf) (a.overflow + c0)[child] = 1;
       }
     }
+  }
+}
+
+// tg_expand_i8 for S = 4 with one 4-lane team per CHILD: child ch = parent * k + c is just "a step of
+// the parent's state with the child's action, written to slot ch", so consecutive teams write
+// consecutive 64-byte children and a wavefront's store is 1 KiB of contiguous memory (the
+// team-per-parent loop in s4_kernel<EXPAND> writes 64-byte pieces 64 k bytes apart).  The k teams of
+// a parent read the same 16-byte parent slices: one request per wavefront, served from L1/L2.  A
+// workgroup takes PB = 64 / k whole parents (k <= 64); lc / k by multiplication (recip = ceil(2^16 / k)).
+__global__ __launch_bounds__(kBlock) void s4_expand_kernel(ApplyArgs a, int PB, int recip) {
+  const int k = a.nact;
+  const int lg = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const int64_t p0 = static_cast<int64_t>(blockIdx.x) * PB;
+  const int nlc = static_cast<int>(min(static_cast<int64_t>(PB), a.B - p0)) * k;  // live children of this workgroup
+  const bool live = lg < nlc;
+  const int lc = live ? lg : nlc - 1;                      // dead teams shadow the last live child
+  const int pl = (lc * recip) >> 16;                       // parent within the workgroup
+  const int64_t c0 = p0 * k;                               // first child of the workgroup
+  const int* tok = reinterpret_cast<const int*>(a.actions + c0 * 12) + lc * 3;
+  const uint32_t du = tok[0], dv = tok[1], dw = tok[2];
+  const uint4 par = *reinterpret_cast<const uint4*>(a.in + p0 * a.in_stride +
+                                                    (__umul24(pl, static_cast<uint32_t>(a.in_stride)) + 16u * q));
+  uint32_t nz = 0;
+  int ovf = 0;
+  const uint4 o = s4_step_slice(par, du, dv, dw, q, a.shift, nz, ovf);
+  if (live) *reinterpret_cast<uint4*>(a.out + c0 * a.out_stride + (__umul24(lc, static_cast<uint32_t>(a.out_stride)) + 16u * q)) = o;
+  const bool any_nz = team_any<4>(nz != 0);
+  const bool any_ovf = team_any<4>((ovf & ~255) != 0);
+  if (q == 0 && live) {
+    (a.done + c0)[lc] = any_nz ? 0 : 1;
+    if (a.changed) {
+      // null action <=> u, v or w is the zero vector <=> all four of its token bytes equal the shift
+      const uint32_t zs = (static_cast<uint32_t>(a.shift) & 0xFFu) * 0x01010101u;
+      const bool in8 = static_cast<unsigned>(a.shift + 128) < 256u;  // otherwise no token equals the shift
+      (a.changed + c0)[lc] = (in8 && (du == zs || dv == zs || dw == zs)) ? 0 : 1;
+    }
+    if (a.overflow && any_ovf) (a.overflow + c0)[lc] = 1;
   }
 }
 
@@ -924,6 +970,16 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
   if (al && a.S == 4 && aligned4(a.actions) && a.in_stride < (1 << 20) && a.out_stride < (1 << 20)) {
     const int64_t blocks = (B * 4 + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
+    if constexpr (MODE == EXPAND) {
+      static const bool per_parent = getenv("TG_S4_EXPAND_PER_PARENT") != nullptr;  // A/B switch for measurements
+      if (a.nact <= 64 && a.out_stride * 64 < (1 << 24) && !per_parent) {
+        const int PB = 64 / a.nact, recip = (65536 + a.nact - 1) / a.nact;
+        const int64_t eblocks = (B + PB - 1) / PB;
+        if (eblocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
+        (void)hipGetLastError(); hipLaunchKernelGGL(s4_expand_kernel, dim3((unsigned)eblocks), dim3(kBlock), 0, st, a, PB, recip);
+        return check_launch(fn);
+      }
+    }
     (void)hipGetLastError(); hipLaunchKernelGGL((s4_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
     return check_launch(fn);
   }
