@@ -15,10 +15,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_graph_S16 -o 
 # 2. the same in eager mode (one ctypes launch per step)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_eager -o bench_eager -- python3 $R/bench.py --mode eager --no-cpu-baseline --no-also > $OUT/bench_eager.json 2> $OUT/bench_eager.err || exit 1
 # 3. HBM traffic counters, one pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass), eager, few steps
-for wl in "4 65536" "4 4194304" "16 8192" "16 131072"; do
+for wl in "4 65536" "4 4194304" "16 8192" "16 131072" "25 4096"; do
   set -- $wl
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_S$1_B$2_$ctr -o pmc -- python3 $R/bench.py --mode eager --steps 56 --warmup 14 --dim $1 --batch $2 --no-cpu-baseline --no-also > $OUT/pmc_S$1_B$2_$ctr.json 2> $OUT/pmc_S$1_B$2_$ctr.err || exit 1
   done
 done
+# 4. the generator of BASELINE config 5 (tokens -> change of basis -> accumulation on the matrix cores)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/generator -o generator -- python3 $R/tools/prof_basis.py > $OUT/generator.log 2> $OUT/generator.err || exit 1
 echo profiles done

@@ -15,7 +15,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = Path(__file__).resolve().parent.parent
 src = root / "gpurun_out" / f"prof_{tag}"
 dst = root / "profiles"
-for name in ("bench_graph", "bench_graph_S16", "bench_eager"):
+for name in ("bench_graph", "bench_graph_S16", "bench_eager", "generator"):
     f = src / name / f"{name}_kernel_stats.csv"
     if f.exists():
         shutil.copy(f, dst / f"{tag}_{name}_kernel_stats.csv")
