@@ -79,9 +79,8 @@ def time_steps(B, S, K, W, dev, mode, seed=0, gid0=0, R=None, sync=None):
     warm_replay = 0
     if mode == "graph":
         # Graphs hold whole 2R cycles wherever possible: such a graph is the same for every chunk (one
-        # instantiation, replayed), and one UNTIMED replay of it brings the state back to the same point of
-        # the schedule.  That matters because the first replay of a hipGraph also uploads it (one-off,
-        # ~0.1 us per node), which is not part of a step.
+        # instantiation, replayed).  Every graph is replayed once UNTIMED before the timed region, because the
+        # first replay of a hipGraph also uploads it (one-off, ~0.1 us per node), which is not part of a step.
         CH = max(L, (2048 // L) * L)  # kernel nodes per graph
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -101,10 +100,14 @@ def time_steps(B, S, K, W, dev, mode, seed=0, gid0=0, R=None, sync=None):
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)  # capture does not execute: the state is still at start_pos
         if not os.environ.get("TG_BENCH_NO_WARM_REPLAY"):
+            # every graph once, in timed order (K steps), then eager steps up to the next multiple of 2R: the
+            # schedule is cyclic, so the state is back at start_pos's point of it, for any K
             for g, _, n in plan:
-                if n % L == 0:
-                    g.replay()
-                    warm_replay += n
+                g.replay()
+                warm_replay += n
+            for j in range((-rem) % L):  # the full-chunk graph is whole cycles; only the remainder leaves a phase
+                launch((start_pos + rem + j) % L)
+                warm_replay += 1
             torch.cuda.synchronize(dev)
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
