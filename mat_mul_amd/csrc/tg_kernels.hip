@@ -769,54 +769,48 @@ __global__ __launch_bounds__(kBlock) void s16_step_kernel(ApplyArgs a) {
   const uint4 uq = *reinterpret_cast<const uint4*>(tok);
   const uint4 wq = *reinterpret_cast<const uint4*>(tok + 32);
   const int vj = tok[16 + (lane & 15)] - a.shift;
-  const int chk = tok[lane < 48 ? lane : 47] - a.shift;  // lane t checks token t
   const int r = lane >> 4;
   const uint32_t ud[4] = {uq.x, uq.y, uq.z, uq.w};
-  int ui[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) ui[n] = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(ud[n]), 8 * r, 8);  // -(u_i)
-  const bool big = __ballot(chk > 31 || chk < -31) != 0;  // wave-uniform
   uint32_t nz = 0, ovf = 0;
-  uint4 res[4];
-  if (!big) {
-    const uint32_t shp = __builtin_amdgcn_perm(static_cast<uint32_t>(a.shift), static_cast<uint32_t>(a.shift), 0x05040100u);
-    uint32_t wp[8];
-    unpack_pairs(wq, wp);
+  const bool inplace = a.in == a.out;
+  int8_t* dst = a.out + g * a.out_stride + 16 * lane;
+  // Saturating int16 form, as in s4_step_slice: with |factor| <= 255 (int8 tokens, |shift| <= 127) u*v and
+  // (u v) w + x are formed exactly and saturate beyond int16, so everything the 16-bit form cannot represent
+  // ends outside int8 -- exactly the results that overflow.  No check of the factors; a chunk whose range
+  // test fails is redone in 32-bit by its lane (wrapped bytes + flag).
+  const uint32_t shp = (static_cast<uint32_t>(a.shift) & 0xFFFFu) | (static_cast<uint32_t>(a.shift) << 16);
+  const bool wide_shift = static_cast<unsigned>(a.shift + 127) > 254u;  // uniform; factors may exceed 255
+  uint32_t wp[8];
+  unpack_pairs(wq, wp);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
+  for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
+  const uint32_t vjp = __builtin_amdgcn_perm(static_cast<uint32_t>(vj), static_cast<uint32_t>(vj), 0x05040100u);
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int uv = mul24_pinned(ui[n], vj);
-      const uint32_t pr = __builtin_amdgcn_perm(static_cast<uint32_t>(uv), static_cast<uint32_t>(uv), 0x05040100u);
-      uint32_t A[8];
-      unpack_pairs(par[n], A);
+  for (int n = 0; n < 4; ++n) {
+    const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(ud[n]), 8 * r, 8);  // -(u_i), i = r + 4 n
+    const uint32_t uip = __builtin_amdgcn_perm(static_cast<uint32_t>(ui), static_cast<uint32_t>(ui), 0x05040100u);
+    const uint32_t pr = pk_mad_i16_sat(uip, vjp, 0u);  // (-u_i v_j) in both halves, saturated
+    uint32_t A[8];
+    unpack_pairs(par[n], A);
 #pragma unroll
-      for (int p = 0; p < 8; ++p) A[p] = pk_mad_i16(pr, wp[p], A[p]);
-      res[n] = pack_pairs(A, nz, ovf);
-    }
-    ovf &= 0xFF00FF00u;
-  } else {  // exact 32-bit form for this game (factors too large for int16 products)
-    if (lane == 0) atomicAdd(&g_fallback_workgroups, 1ull);
-    const uint32_t wd[4] = {wq.x, wq.y, wq.z, wq.w};
-    int o32 = 0;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int uv = ui[n] * vj;
-      int acc[16];
+    for (int p = 0; p < 8; ++p) A[p] = pk_mad_i16_sat(pr, wp[p], A[p]);
+    uint32_t cnz = 0, c16 = 0;
+    uint4 res = pack_pairs(A, cnz, c16);
+    if (__builtin_expect(wide_shift || (c16 & 0xFF00FF00u), 0)) {  // rare: exact 32-bit form of this chunk
+      const uint32_t wd[4] = {wq.x, wq.y, wq.z, wq.w};
+      const int uv = ui * vj;
+      int acc[16], o32 = 0;
+      cnz = 0;
       unpack16(par[n], acc);
 #pragma unroll
       for (int t = 0; t < 16; ++t) acc[t] += uv * (sbyte(wd[t >> 2], t & 3) - a.shift);
-      res[n] = pack16(acc, nz, o32);
+      res = pack16(acc, cnz, o32);
+      ovf |= static_cast<uint32_t>(o32) & ~255u;
     }
-    ovf = static_cast<uint32_t>(o32) & ~255u;
-  }
-  const bool inplace = a.in == a.out;
-  int8_t* dst = a.out + g * a.out_stride + 16 * lane;
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const bool same = inplace && res[n].x == par[n].x && res[n].y == par[n].y && res[n].z == par[n].z &&
-                      res[n].w == par[n].w;  // untouched rows need no store in place
-    if (live && !same) *reinterpret_cast<uint4*>(dst + 1024 * n) = res[n];
+    nz |= cnz;
+    // stored as soon as it is final; in place, rows the action left untouched need no store
+    const bool same = inplace && res.x == par[n].x && res.y == par[n].y && res.z == par[n].z && res.w == par[n].w;
+    if (live && !same) *reinterpret_cast<uint4*>(dst + 1024 * n) = res;
   }
   const bool any_nz = __ballot(nz != 0) != 0;
   const bool any_ovf = __ballot(ovf != 0) != 0;
