@@ -29,6 +29,20 @@ __device__ __forceinline__ int mul24_pinned(int a, int b) {
   return r;
 }
 
+// a*b + c, same operand range, as ONE v_mad_i32_i24 (low 32 bits of the exact result)
+__device__ __forceinline__ int mad24_pinned(int a, int b, int c) {
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// the same with a wave-uniform first factor kept in an SGPR (one scalar operand per VOP3 is allowed)
+__device__ __forceinline__ int mad24_sgpr(int a_uniform, int b, int c) {
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "s"(a_uniform), "v"(b), "v"(c));
+  return r;
+}
+
 // number of non-zero bytes of a dword: fold each byte onto its low bit, then popcount
 __device__ __forceinline__ int count_nonzero_bytes(uint32_t x) {
   x |= x >> 4;

@@ -50,7 +50,11 @@ struct ApplyArgs {
   int S;
   int nact;
   int shift;
+  int only_flagged;      // MANY: redo only the games whose done_step is kNeedsExact (second pass after tg_mfma.h)
 };
+
+// done_step value by which many_mfma_kernel hands a game to the lattice kernels (never a valid result)
+constexpr int32_t kNeedsExact = INT32_MIN;
 
 // =============================================================================================
 // slow path: any S, any alignment.  One workgroup per game, one byte per thread-iteration.
@@ -948,8 +952,9 @@ unsigned capped_grid(int64_t blocks) {
 }
 
 template <int MODE>
-int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
+int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
   using namespace tg;
+  ApplyArgs a = a_in;
   if (a.B == 0) return TG_OK;
   const bool al = (MODE == GENF || (aligned16(a.in) && a.in_stride % 16 == 0)) && aligned16(a.out) &&
                   a.out_stride % 16 == 0;
@@ -1046,6 +1051,48 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a, hipStream_t st) {
       if (a.S == 25) TG_MFMA(25);
 #undef TG_MFMA_K
 #undef TG_MFMA
+    }
+  }
+  if constexpr (MODE == MANY) {
+    // K fused steps: the final state is one accumulation on the matrix cores; games it cannot certify (a step
+    // may have left int8, or the zero state was reached before the last step) are flagged through done_step and
+    // redone by the lattice kernels below, launched with only_flagged (tg_mfma.h)
+    // Where it pays (measured, tools/sweep_many.py): the per-game set-up (transposed factors, input image,
+    // per-action scalars, verdict) outweighs the lattice kernels' K S^3 MACs only for long action lists; beyond
+    // K = 127 the overflow bound cannot certify the reference's {-1,0,1} factors any more.
+    static const bool many_always = getenv("TG_MFMA_MANY_ALWAYS") != nullptr;  // tests: every eligible shape
+    const bool pays = a.nact <= 127 && ((a.S == 25 && a.nact >= 12) || (a.S == 16 && a.nact >= 40));
+    if (al && a.nact <= 256 && !force_i32 && !no_mfma && (a.S == 9 || a.S == 16 || a.S == 25) && (pays || many_always)) {
+      const int Rp = (a.nact + 31) & ~31;
+#define TG_MANY_K(S_, KS_)                                                                       \
+  do {                                                                                           \
+    const int ldsb = many_mfma_lds_bytes<S_>(Rp);                                                \
+    static int occ_lds = -1, occ_val = 1;                                                        \
+    if (occ_lds != ldsb) {                                                                       \
+      int v = 0;                                                                                 \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, many_mfma_kernel<S_, KS_>, kBlock, ldsb) != hipSuccess || v < 1) v = 1; \
+      occ_val = v;                                                                               \
+      occ_lds = ldsb;                                                                            \
+    }                                                                                            \
+    const int64_t resident = static_cast<int64_t>(occ_val) * device_cu_count();                  \
+    const int64_t per_wg = (B + resident - 1) / resident;                                        \
+    const int64_t grid = (B + per_wg - 1) / per_wg;                                              \
+    (void)hipGetLastError();                                                                     \
+    hipLaunchKernelGGL((many_mfma_kernel<S_, KS_>), dim3((unsigned)grid), dim3(kBlock), ldsb, st, a, Rp); \
+    if (int rc = check_launch(fn)) return rc;                                                    \
+  } while (0)
+#define TG_MANY(S_)                                                                              \
+  do {                                                                                           \
+    if (Rp == 32) TG_MANY_K(S_, 1);                                                              \
+    else if (Rp == 64) TG_MANY_K(S_, 2);                                                         \
+    else TG_MANY_K(S_, 0);                                                                       \
+  } while (0)
+      if (a.S == 9) TG_MANY(9);
+      if (a.S == 16) TG_MANY(16);
+      if (a.S == 25) TG_MANY(25);
+#undef TG_MANY
+#undef TG_MANY_K
+      a.only_flagged = 1;
     }
   }
   static const bool no_rows = getenv("TG_NO_ROWS") != nullptr;  // A/B switch for measurements

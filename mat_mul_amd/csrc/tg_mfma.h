@@ -228,3 +228,333 @@ __global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) 
     __syncthreads();  // T and the image are reused by the next game
   }
 }
+
+// =============================================================================================
+// tg_step_many_i8 on the matrix cores: out = in - sum_k A_k, done_step, overflow.
+//
+// The final state is one more accumulation (the input enters through an identity fragment:
+// D[l][n] += sum_l' I[l][l'] X0[n][l'] puts X0 into the accumulators in the result's own layout, so it
+// costs one MFMA per tile and no unpacking).  What a sum cannot give directly is what happened BETWEEN
+// the K steps; both questions are answered exactly, with the fast path as a filter:
+//   * overflow: every prefix P_k = P_K + sum_{r>k} A_r, so |P_k| <= max|P_K| + sum_r mu_r mv_r mw_r
+//     (m?_r = largest |factor| of action r).  If that bound is <= 127 no step can have left int8.
+//   * done_step: two linear functionals h(X) = sum c[i,j,l] X[i,j,l] mod 2^32 with rank-1 weights
+//     c = pu (x) pv (x) pw, so h(A_r) = (pu.u_r)(pv.v_r)(pw.w_r) costs 3S MACs per action, and h(X0) comes
+//     out of two spare rows of the identity fragment (pw) times a per-column weight (pu[i] pv[j]).
+//     P_k = 0 implies h(P_k) = 0, so the first zero state is the first k where both functionals vanish --
+//     or a false positive (probability ~2^-64).  A candidate at k = K-1 is checked against the final
+//     state, which is already there.
+// Games that fail the bound, have a candidate before K-1, or have factors beyond the byte-product range
+// are NOT written: their done_step is set to kNeedsExact and the lattice kernels (tg_rows.h / tg_packed.h),
+// launched right after with ApplyArgs::only_flagged, redo exactly those games.
+// =============================================================================================
+// inclusive prefix sum over the 64 lanes of a wavefront, all in the VALU (DPP row shifts and row broadcasts)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+
+struct FunctionalWeights {
+  int uv[2][2][32];  // [functional][u or v][index]: odd, 11 bits, signed: pu*pv fits 22 bits (24-bit multiplies)
+  int w[2][32];      // [functional][index]: odd, int8 (they ride in the identity fragment)
+};
+constexpr FunctionalWeights make_functional_weights() {
+  FunctionalWeights t{};
+  uint32_t s = 0x9E3779B9u;
+  for (int m = 0; m < 2; ++m) {
+    for (int x = 0; x < 2; ++x)
+      for (int i = 0; i < 32; ++i) {
+        s = s * 1664525u + 1013904223u;
+        t.uv[m][x][i] = static_cast<int>((s >> 21) | 1u) - (1 << 10);
+      }
+    for (int i = 0; i < 32; ++i) {
+      s = s * 1664525u + 1013904223u;
+      t.w[m][i] = static_cast<int>((s >> 24) | 1u) - 128;
+    }
+  }
+  return t;
+}
+__constant__ FunctionalWeights g_fw = make_functional_weights();
+
+template <int S>
+constexpr int many_mfma_lds_bytes(int Rp) {
+  return MGeo<S>::TROWS * (Rp + 16) + MGeo<S>::IMG + 32 + 32 + 8 * MGeo<S>::NT * 32 + 36 * Rp;
+}
+
+template <int S, int KS>
+__global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int Rp) {
+  using G = MGeo<S>;
+  static_assert((S % 8) < 3, "the two functional rows S, S+1 must be rows of the lower half-wave");
+  extern __shared__ __attribute__((aligned(16))) uint8_t mfma_smem[];
+  if constexpr (KS != 0) Rp = 32 * KS;
+  const int RS = Rp + 16;
+  int8_t* const T = reinterpret_cast<int8_t*>(mfma_smem);
+  uint8_t* const img = mfma_smem + G::TROWS * RS;
+  int* const red = reinterpret_cast<int*>(img + G::IMG + 32);  // [0,1] h(X0), [2] max |final|
+  uint32_t* const cw = reinterpret_cast<uint32_t*>(red + 8);    // [2][NT*32] column weights pu[i] pv[j]
+  int* const sdot = reinterpret_cast<int*>(cw + 2 * G::NT * 32);  // [2][3][Rp]
+  int* const smx = sdot + 6 * Rp;                                 // [3][Rp]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int R = a.nact;
+
+  for (int e = tid; e < (32 - S) * RS; e += kBlock) T[(3 * S) * RS + e] = 0;
+  for (int n = tid; n < G::NT * 32; n += kBlock) {
+    const int nn = n < G::S2 ? n : G::S2 - 1;
+    const int i = nn / S, j = nn - i * S;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      cw[m * G::NT * 32 + n] = n < G::S2 ? static_cast<uint32_t>(g_fw.uv[m][0][i] * g_fw.uv[m][1][j]) : 0u;
+  }
+
+  constexpr int NRG = kBlock / G::A3;
+  constexpr int TB = 6;
+  const int sx = tid % G::A3, srg = tid / G::A3;
+  const int slo = sx < 2 * S ? -G::UVLIM : -128, shi = sx < 2 * S ? G::UVLIM : 127;
+
+  constexpr int NW = kBlock / 64, TPW = (G::NT + NW - 1) / NW;
+  int uoff[TPW], voff[TPW], ncol[TPW], xoff[TPW];
+#pragma unroll
+  for (int k = 0; k < TPW; ++k) {
+    const int n = 32 * (wave + NW * k) + col;
+    const int nn = n < G::S2 ? n : G::S2 - 1;
+    const int i = nn / S, j = nn - i * S;
+    uoff[k] = i * RS + 16 * h;
+    voff[k] = (S + j) * RS + 16 * h;
+    ncol[k] = n < G::S2 ? n : -1;
+    xoff[k] = nn * S + 16 * h;  // this lane's 16 bytes of X0's column nn (bytes past the column meet zero rows)
+  }
+  const int woff = (2 * S + col) * RS + 16 * h;
+  // identity fragment with the two functional rows: row l = col, k = 16 h + j
+  v4i ida;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = 16 * h + 4 * d + t;
+      int v = 0;
+      if (k < S) v = col < S ? (k == col) : (col == S ? g_fw.w[0][k] : (col == S + 1 ? g_fw.w[1][k] : 0));
+      w |= static_cast<uint32_t>(v & 255) << (8 * t);
+    }
+    ida[d] = static_cast<int>(w);
+  }
+  constexpr int kF0 = (S & 3) + 4 * (S >> 3), kF1 = ((S + 1) & 3) + 4 * ((S + 1) >> 3);  // registers of rows S, S+1 (h = 0)
+
+  for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
+    // ---- 1. factors (u negated: the products are subtracted), transposed into LDS; X0 into the image ----
+    const int8_t* tok = a.actions + g * R * G::A3;
+    int big = 0;
+    if (srg < NRG) {
+      for (int rb = 4 * srg; rb < Rp; rb += 4 * NRG * TB) {
+        int f[TB][4];
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int r = rb + 4 * NRG * tb + t;
+            f[tb][t] = tok[static_cast<uint32_t>(sx + min(r, R - 1) * G::A3)];
+          }
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+          const int r0 = rb + 4 * NRG * tb;
+          if (r0 < Rp) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              f[tb][t] = (r0 + t < R) ? f[tb][t] - a.shift : 0;
+              big |= (f[tb][t] < slo) | (f[tb][t] > shi);
+              if (sx < S) f[tb][t] = -f[tb][t];
+            }
+            *reinterpret_cast<uint32_t*>(T + sx * RS + r0) = pack4(f[tb][0], f[tb][1], f[tb][2], f[tb][3]);
+          }
+        }
+      }
+    }
+    {
+      const int8_t* src = a.in + g * a.in_stride;
+      for (int c = tid; c < G::NCHUNK; c += kBlock)
+        *reinterpret_cast<uint4*>(img + 16 * c) = load_chunk<G::TAIL>(src + 16 * c, c == G::NCHUNK - 1);
+    }
+    if (tid < 8) red[tid] = 0;
+    if (__syncthreads_or(big)) {  // factors beyond the byte products: the lattice kernels take this game
+      if (tid == 0) a.done_step[g] = kNeedsExact;
+      __syncthreads();
+      continue;
+    }
+
+    // ---- 2a. per-action scalars: wavefront x < 3 takes factor vector x of every action ----
+    if (wave < 3) {
+      const int uw = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: the weights come by scalar loads
+      const int* wu0 = uw == 2 ? g_fw.w[0] : g_fw.uv[0][uw];
+      const int* wu1 = uw == 2 ? g_fw.w[1] : g_fw.uv[1][uw];
+      for (int r = lane; r < Rp; r += 64) {
+        int d0 = 0, d1 = 0, mx = 0;
+        const int8_t* colp = T + (uw * S) * RS + r;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          const int b = colp[i * RS];
+          d0 = mad24_sgpr(wu0[i], b, d0);
+          d1 = mad24_sgpr(wu1[i], b, d1);
+          mx = max(mx, max(b, -b));
+        }
+        sdot[(0 * 3 + wave) * Rp + r] = d0;
+        sdot[(1 * 3 + wave) * Rp + r] = d1;
+        smx[wave * Rp + r] = mx;
+      }
+    }
+    __syncthreads();
+    // every wavefront: sum_r mu_r mv_r mw_r.  Above 127 the overflow bound cannot hold whatever the final state
+    // is: hand the game over now, before the expensive part
+    int bound = 0;
+    for (int r0 = 0; r0 < Rp; r0 += 64) {
+      const int r = r0 + lane;
+      int pb = 0;
+      if (r < R) pb = min(smx[r] * smx[Rp + r], 1 << 12) * smx[2 * Rp + r];  // <= 2^20: the sum cannot wrap
+      bound += static_cast<int>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_scan(static_cast<uint32_t>(pb))), 63));
+      if (bound > (1 << 24)) bound = 1 << 24;
+    }
+    if (bound > 127) {  // workgroup-uniform
+      if (tid == 0) a.done_step[g] = kNeedsExact;
+      __syncthreads();
+      continue;
+    }
+
+    // ---- 2b. column tiles: acc = I X0 + W P ----
+    int hi = 0, lo = 0;
+    uint32_t hx0 = 0, hx1 = 0;
+    v4i wa[KS ? KS : 1];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) wa[k] = *reinterpret_cast<const v4i*>(T + woff + 32 * k);
+    auto tile = [&](int k, uint32_t (&X)[4]) {
+      v16i acc;
+#pragma unroll
+      for (int t2 = 0; t2 < 16; ++t2) acc[t2] = 0;
+      {  // X0 fragment: 16 bytes at image offset xoff (any alignment) from aligned dwords
+        const int m = xoff[k] & 3;
+        const uint32_t* p4 = reinterpret_cast<const uint32_t*>(img + (xoff[k] & ~3));
+        uint32_t d[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) d[t] = p4[t];
+        v4i xf;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xf[t] = static_cast<int>(__builtin_amdgcn_alignbyte(d[t + 1], d[t], static_cast<uint32_t>(m)));
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ida, xf, acc, 0, 0, 0);
+      }
+      if constexpr (KS != 0) {
+        v4i p[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          p[ks] = bytemul16(*reinterpret_cast<const v4i*>(T + uoff[k] + 32 * ks),
+                            *reinterpret_cast<const v4i*>(T + voff[k] + 32 * ks));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa[ks], p[ks], acc, 0, 0, 0);
+      } else {
+        for (int k0 = 0; k0 < Rp; k0 += 32) {
+          const v4i w = *reinterpret_cast<const v4i*>(T + woff + k0);
+          const v4i p = bytemul16(*reinterpret_cast<const v4i*>(T + uoff[k] + k0),
+                                  *reinterpret_cast<const v4i*>(T + voff[k] + k0));
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, p, acc, 0, 0, 0);
+        }
+      }
+      // rows S, S+1 of the lower half-wave: sum_l pw[l] X0[n][l] for this lane's column
+      if (h == 0 && ncol[k] >= 0) {
+        const int n = 32 * (wave + NW * k) + col;
+        hx0 += static_cast<uint32_t>(mul24_pinned(static_cast<int>(cw[n]), acc[kF0]));  // |cw| < 2^22, |t| < 2^20
+        hx1 += static_cast<uint32_t>(mul24_pinned(static_cast<int>(cw[G::NT * 32 + n]), acc[kF1]));
+      }
+      acc[kF0] = 0;
+      acc[kF1] = 0;
+#pragma unroll
+      for (int t2 = 0; t2 < 16; t2 += 2) {
+        hi = max(max(acc[t2], acc[t2 + 1]), hi);
+        lo = min(min(acc[t2], acc[t2 + 1]), lo);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) X[q] = pack4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+      asm volatile("" : "+v"(hi), "+v"(lo), "+v"(hx0), "+v"(hx1), "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]));
+    };
+#pragma unroll
+    for (int k = 0; k < TPW; k += 2) {
+      if (G::NT % NW != 0 && wave + NW * k >= G::NT) break;
+      __builtin_amdgcn_sched_barrier(0);
+      uint32_t XA[4], XB[4] = {0, 0, 0, 0};
+      tile(k, XA);
+      const bool pair = k + 1 < TPW && (G::NT % NW == 0 || wave + NW * (k + 1) < G::NT);
+      if (pair) tile(k + 1, XB);
+      uint32_t E[9];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(XA[q], XB[q], false, false);
+        E[2 * q] = sw[0];
+        E[2 * q + 1] = sw[1];
+      }
+      E[8] = 0;
+      const int nown = h ? (pair ? ncol[k + 1 < TPW ? k + 1 : k] : -1) : ncol[k];
+      constexpr int Q = (S + 3) / 4, r4 = S % 4;
+      static_assert(r4 <= 1, "tg_mfma.h: column emission handles S % 4 in {0, 1}");
+      if constexpr (r4 == 1) {
+        const uint32_t nxt = __builtin_amdgcn_update_dpp(0u, E[0], 0x130, 0xf, 0xf, false);
+        E[Q - 1] |= nxt << 8;
+      }
+      if (nown >= 0) {  // in place over the X0 bytes this pair has consumed (tiles are 16-byte aligned blocks)
+        const int base = nown * S;
+        const int o = (4 - (base & 3)) & 3;
+        uint8_t* dst = img + base + o;
+#pragma unroll
+        for (int jd = 0; jd < Q; ++jd) {
+          if (4 * jd + o < S) {
+            const uint32_t d = __builtin_amdgcn_alignbyte(E[jd + 1], E[jd], static_cast<uint32_t>(o));
+            *reinterpret_cast<uint32_t*>(dst + 4 * jd) = d;
+          }
+        }
+      }
+    }
+    if (hx0) atomicAdd(reinterpret_cast<unsigned*>(&red[0]), hx0);
+    if (hx1) atomicAdd(reinterpret_cast<unsigned*>(&red[1]), hx1);
+    const int mabs = max(hi, -lo);
+    if (mabs) atomicMax(&red[2], mabs);
+    __syncthreads();  // image, action scalars and reductions complete
+
+    // ---- 3. verdict (every wavefront computes it: no further exchange) ----
+    bool redo;
+    int dstep;
+    {
+      const uint32_t h0 = static_cast<uint32_t>(red[0]), h1 = static_cast<uint32_t>(red[1]);
+      const int maxfinal = red[2];
+      uint32_t carry0 = 0, carry1 = 0;
+      int first = -1;
+      for (int r0 = 0; r0 < Rp; r0 += 64) {
+        const int r = r0 + lane;
+        uint32_t g0 = 0, g1 = 0;
+        if (r < R) {
+          g0 = static_cast<uint32_t>(sdot[0 * Rp + r]) * static_cast<uint32_t>(sdot[1 * Rp + r]) * static_cast<uint32_t>(sdot[2 * Rp + r]);
+          g1 = static_cast<uint32_t>(sdot[3 * Rp + r]) * static_cast<uint32_t>(sdot[4 * Rp + r]) * static_cast<uint32_t>(sdot[5 * Rp + r]);
+        }
+        g0 = wave_inclusive_scan(g0);
+        g1 = wave_inclusive_scan(g1);
+        const bool cand = r < R && (h0 + carry0 + g0) == 0u && (h1 + carry1 + g1) == 0u;
+        const unsigned long long mask = __ballot(cand);
+        if (first < 0 && mask) first = r0 + __builtin_ctzll(mask);
+        carry0 += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(g0), 63));
+        carry1 += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(g1), 63));
+      }
+      const bool final_zero = maxfinal == 0;
+      redo = maxfinal + bound > 127;                           // a step may have left int8
+      redo |= first >= 0 && first < R - 1;                     // a candidate that the final state cannot confirm
+      redo |= final_zero && first != R - 1;                    // cannot happen; never trust it silently
+      dstep = (first == R - 1 && final_zero) ? R - 1 : -1;
+    }
+    if (!redo) {
+      int8_t* out = a.out + g * a.out_stride;
+      for (int c = tid; c < G::NCHUNK; c += kBlock)
+        store_chunk<G::TAIL>(out + 16 * c, *reinterpret_cast<const uint4*>(img + 16 * c), c == G::NCHUNK - 1);
+    }
+    if (tid == 0) a.done_step[g] = redo ? kNeedsExact : dstep;
+    __syncthreads();
+  }
+}

@@ -66,6 +66,16 @@ __device__ __forceinline__ int load_tokens_checked(const int8_t* src, int nbytes
 // Do all factors of this workgroup's games fit the 16-bit path?  Single tile (nact <= at): the
 // check rides on the tile's own raw load (left in LDS, head0 set).  Several tiles: every token is
 // scanned first, because the state must not be touched before the decision.  Workgroup-uniform.
+// second pass of step_many (ApplyArgs::only_flagged): is game b one of those to redo?  Uniform per game.
+template <int MODE>
+__device__ __forceinline__ bool flagged_or_all(const ApplyArgs& a, int64_t b) {
+  if constexpr (MODE == MANY) {
+    // read by every thread before the game's slow_game (which ends with a barrier) rewrites done_step
+    return !a.only_flagged || a.done_step[b] == kNeedsExact;
+  }
+  return true;
+}
+
 template <int TS>
 __device__ __forceinline__ bool factors_too_large(const int8_t* tok, int nact, int at, int tok_per_action,
                                                   int8_t* raw, int lt, int shift, int flim, int& head0) {
@@ -187,8 +197,14 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
   const int tid = threadIdx.x;
   const int team = tid / TS, lt = tid % TS;
   int64_t g = static_cast<int64_t>(blockIdx.x) * G::GPB + team;
-  const bool live = g < a.B;
+  bool live = g < a.B;
   if (!live) g = a.B - 1;
+  if constexpr (MODE == MANY) {
+    if (a.only_flagged) {  // second pass: only the games many_mfma_kernel handed over
+      live = live && a.done_step[g] == kNeedsExact;
+      if (!__syncthreads_or(live)) return;
+    }
+  }
   const int8_t* const tok = a.actions + g * a.nact * (3 * S);
   int8_t* const raw = raw_all + team * raw_stride;
 
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
     note_fallback();
     for (int t = 0; t < G::GPB; ++t) {
       const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
-      if (b < a.B) slow_game<MODE>(a, b, flags);
+      if (b < a.B && flagged_or_all<MODE>(a, b)) slow_game<MODE>(a, b, flags);
     }
     return;
   }

@@ -61,8 +61,14 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
   const int tid = threadIdx.x;
   const int team = tid / TS, lt = tid % TS;
   int64_t g = static_cast<int64_t>(blockIdx.x) * G::GPB + team;
-  const bool live = g < a.B;
+  bool live = g < a.B;
   if (!live) g = a.B - 1;
+  if constexpr (MODE == MANY) {
+    if (a.only_flagged) {  // second pass: only the games many_mfma_kernel handed over
+      live = live && a.done_step[g] == kNeedsExact;
+      if (!__syncthreads_or(live)) return;
+    }
+  }
   const int8_t* const tok = a.actions + g * a.nact * (3 * S);
   int8_t* const raw = raw_all + team * raw_stride;
   uint8_t* const tab = tab_all + team * (at * G::TAB_BYTES);
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
     note_fallback();
     for (int t = 0; t < G::GPB; ++t) {
       const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
-      if (b < a.B) slow_game<MODE>(a, b, flags);
+      if (b < a.B && flagged_or_all<MODE>(a, b)) slow_game<MODE>(a, b, flags);
     }
     return;
   }
