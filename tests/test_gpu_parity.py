@@ -219,6 +219,59 @@ def test_step_extreme_factors_full_int8_range(S):
             assert not want_ovf[0::4].any() and want_ovf.any()
 
 
+@pytest.mark.parametrize("S,K", [(25, 12), (25, 40), (25, 64), (25, 127), (16, 40), (16, 64), (16, 100)])
+def test_step_many_matrix_core_path_verdicts(S, K):
+    """tg_mfma.h many_mfma_kernel certifies a game only when its overflow bound holds and the zero state is
+    reached at the last step or never; everything else goes to the lattice kernels through done_step.  One
+    batch with every kind of game, all bit-exact against the oracle (state, done_step, overflow):
+    demo replays (done at K-1), early termination (the tail of the action list cancels), never done,
+    start at zero, a step that overflows in the middle but returns, large factors, and games that pass
+    through zero and leave again."""
+    rng = np.random.default_rng(31 * S + K)
+    B = 24
+    thr = O.categorical_thresholds((0.15, 0.7, 0.15))
+    tok, tgt, _ = O.gen_demos_i8(B, S, K, thr, (-1, 0, 1), 1, seed=S + K)
+    st = tgt.copy()
+    ac = tok.copy()
+    # 0..5: plain replays: done exactly at K-1 (or earlier if terms cancel)
+    # 6..8: the last two actions are a term and its negation: the state is zero at K-3 already
+    for b in (6, 7, 8):
+        ac[b, K - 2] = tok[b, 0]
+        ac[b, K - 1] = tok[b, 0]
+        ac[b, K - 1, :S] = 2 - tok[b, 0, :S]
+        st[b] = O.gen_from_factors_i8(ac[b:b + 1, :K - 2], 1)[0][0]
+    # 9..11: never done (random start state)
+    st[9:12] = rng.integers(-3, 4, size=(3, S, S, S))
+    # 12: starts at zero, first action is null -> done at step 0, then leaves zero
+    st[12] = 0
+    ac[12, 0] = 1
+    # 13: a dense action pushes entries beyond int8 in the middle, its negation brings them back
+    ac[13, 3] = 2
+    ac[13, 3, 2 * S:] = 2
+    st[13] = np.clip(st[13].astype(int) - 126, -128, 127).astype(np.int8)
+    ac[13, 4] = ac[13, 3]
+    ac[13, 4, :S] = 0
+    # 14: factors beyond the byte-product range (|u| = 12)
+    ac[14, 1, 0] = 13
+    # 15: full int8 w
+    ac[15, 2, 2 * S:] = rng.integers(-127, 128, size=S)
+    # 16..17: {-2..2} vocabulary: the scalar bound fails, the lattice kernels certify
+    ac[16:18] = rng.integers(-1, 4, size=(2, K, 3 * S))
+    # 18: passes through zero at step 5 and leaves again
+    st[18] = O.gen_from_factors_i8(ac[18:19, :6], 1)[0][0]
+    want, want_ds, want_ovf = O.step_many_i8(st, ac)
+    assert (want_ds[:6] >= 0).all() and (want_ds[6:9] == K - 3).all() and (want_ds[9:12] == -1).all()
+    assert want_ds[12] == 0 and want_ovf[13] == 1 and want_ds[18] == 5
+    ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    out, ds = ops.step_many(padded(st), dev(ac), overflow=ovf)
+    assert np.array_equal(host(out), want) and np.array_equal(host(ds), want_ds) and np.array_equal(host(ovf), want_ovf)
+    # in place
+    t = padded(st)
+    ovf.zero_()
+    ops.step_many(t, dev(ac), out=t, overflow=ovf)
+    assert np.array_equal(host(t), want) and np.array_equal(host(ovf), want_ovf)
+
+
 @pytest.mark.parametrize("S", [9, 16, 25])
 @pytest.mark.parametrize("R", [1, 31, 32, 33, 64, 65, 100, 256, 257])
 def test_gen_from_factors_matrix_core_path(S, R):
@@ -677,7 +730,7 @@ print("AB_OK")
 '''
 
 
-@pytest.mark.parametrize("env_name", ["TG_FORCE_I32", "TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA"])
+@pytest.mark.parametrize("env_name", ["TG_FORCE_I32", "TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA", "TG_MFMA_MANY_ALWAYS"])
 def test_ab_switch_paths_stay_exact(env_name, tmp_path):
     """The measurement switches (32-bit cursor kernels; packed chunks instead of rows) select
     kernels that the default dispatch no longer uses -- they must stay bit-exact too."""
