@@ -305,7 +305,7 @@ def main():
                              "roofline": roofline(b2, s2, k2, r2["event_ms"])})
             from mat_mul_amd import ops
             # the fused path, labelled separately: K actions per launch, state stays on chip
-            for (s2, b2, k2) in [(4, 65536, 7), (16, 8192, 20)]:
+            for (s2, b2, k2) in [(4, 65536, 7), (16, 8192, 20), (25, 4096, 64)]:
                 tok, tgt = ops.gen_demos(b2, s2, k2, dev, seed=2)
                 st2 = ops.alloc_states(b2, s2, dev)
                 ds = torch.zeros(b2, dtype=torch.int32, device=dev)
