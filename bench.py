@@ -295,7 +295,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(Bg, S)
         if world == 1 and not args.no_also:
             also = []
-            for (s2, b2, k2, label) in [(16, 8192, 512, "BASELINE config 3"), (4, 1 << 22, 112, "HBM-streaming batch (268 MB of states)"),
+            for (s2, b2, k2, label) in [(16, 8192, 512, "BASELINE config 3"), (4, 1 << 17, 1008, "BASELINE config 4 per-GPU share at 8 GPUs"),
+                                        (4, 1 << 22, 112, "HBM-streaming batch (268 MB of states)"),
                                         (25, 4096, 208, "config 5 per-GPU step"), (16, 1 << 17, 64, "HBM-streaming batch (537 MB of states)")]:
                 if s2 == S and b2 == Bg:
                     continue
