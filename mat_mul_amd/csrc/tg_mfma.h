@@ -106,7 +106,10 @@ __global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) 
 
   for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
     // ---- 1. factors of this game, transposed into LDS (4 actions = one dword); range check; r >= R -> 0 ----
-    const int8_t* tok = a.actions + g * R * G::A3;  // uniform; lane offsets are 32-bit
+    // buffer loads: one VGPR of lane offset + immediates instead of 24 64-bit addresses, and rows r >= R fall
+    // outside num_records (they read as 0), so no clamping
+    const __amdgpu_buffer_rsrc_t tok = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int8_t*>(a.actions + g * R * G::A3), 0, R * G::A3, 0x00027000);
     int big = 0;
     if (srg < NRG) {
       for (int rb = 4 * srg; rb < Rp; rb += 4 * NRG * TB) {
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) 
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int r = rb + 4 * NRG * tb + t;
-            f[tb][t] = tok[static_cast<uint32_t>(sx + min(r, R - 1) * G::A3)];  // unsigned: SGPR base + 32-bit lane offset
+            f[tb][t] = static_cast<int8_t>(__builtin_amdgcn_raw_buffer_load_b8(tok, sx + r * G::A3, 0, 0));
           }
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb) {
@@ -348,7 +351,8 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
 
   for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
     // ---- 1. factors (u negated: the products are subtracted), transposed into LDS; X0 into the image ----
-    const int8_t* tok = a.actions + g * R * G::A3;
+    const __amdgpu_buffer_rsrc_t tok = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int8_t*>(a.actions + g * R * G::A3), 0, R * G::A3, 0x00027000);
     int big = 0;
     if (srg < NRG) {
       for (int rb = 4 * srg; rb < Rp; rb += 4 * NRG * TB) {
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int r = rb + 4 * NRG * tb + t;
-            f[tb][t] = tok[static_cast<uint32_t>(sx + min(r, R - 1) * G::A3)];
+            f[tb][t] = static_cast<int8_t>(__builtin_amdgcn_raw_buffer_load_b8(tok, sx + r * G::A3, 0, 0));
           }
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb) {
