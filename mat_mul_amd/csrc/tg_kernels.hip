@@ -1061,7 +1061,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     // per-action scalars, verdict) outweighs the lattice kernels' K S^3 MACs only for long action lists; beyond
     // K = 127 the overflow bound cannot certify the reference's {-1,0,1} factors any more.
     static const bool many_always = getenv("TG_MFMA_MANY_ALWAYS") != nullptr;  // tests: every eligible shape
-    const bool pays = a.nact <= 127 && ((a.S == 25 && a.nact >= 12) || (a.S == 16 && a.nact >= 40));
+    const bool pays = a.nact <= 127 && ((a.S == 25 && a.nact >= 12) || (a.S == 16 && a.nact >= 40) || (a.S == 9 && a.nact >= 48));
     if (al && a.nact <= 256 && !force_i32 && !no_mfma && (a.S == 9 || a.S == 16 || a.S == 25) && (pays || many_always)) {
       const int Rp = (a.nact + 31) & ~31;
 #define TG_MANY_K(S_, KS_)                                                                       \
