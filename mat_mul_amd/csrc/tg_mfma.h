@@ -1,22 +1,27 @@
-// tg_mfma.h -- the generator's accumulation on the matrix cores (included by tg_kernels.hip).
+// tg_mfma.h -- accumulation over many rank-1 terms on the matrix cores (included by tg_kernels.hip):
+// genf_mfma_kernel (tg_gen_from_factors_i8, the generator) and many_mfma_kernel (tg_step_many_i8, below).
 //
 // target[i][j][l] = sum_r u_r[i] v_r[j] w_r[l]   (reference utils.py:218-232, datasets.py:127-141)
 //
-// is the one dense contraction on the path: per game a (32 x R) by (R x S^2) integer product,
+// is the dense contraction on the path: per game a (32 x R) by (R x S^2) integer product,
 //     D[l][(i,j)] = sum_r  W[l][r] * P[r][(i,j)],      P[r][(i,j)] = u_r[i] * v_r[j],
 // with R ops per output byte (R = 64 at BASELINE config 5) -- compute-bound on the vector ALU
 // (tg_rows.h: 117 us for 4096 games at S = 25, R = 64, 44 % of the v_pk_mad_i16 rate), a small
-// fraction of the int8 MFMA rate.  One workgroup per game:
+// fraction of the int8 MFMA rate.  One workgroup per game at a time (several games per workgroup):
 //   1. the game's R x 3S factors (token - shift) are written to LDS TRANSPOSED, T[x][r], so that
-//      the 16 consecutive r a lane needs are one ds_read_b128;
+//      the 16 consecutive r a lane needs are one ds_read_b128 (tokens arrive by buffer loads: one
+//      offset register, rows past R read as zero);
 //   2. a wavefront owns column tiles of 32 columns n = (i,j).  Per 32 values of r: the A fragment is
 //      W (row l = lane & 31), the B fragment is built by the lane for its column: 16 byte products
 //      u_r[i] * v_r[j] (v_mul_i32_i24 with SDWA byte selects, written straight into the bytes of the
 //      fragment), then one v_mfma_i32_32x32x32_i8.  Products must fit int8: |u|, |v| <= 11
 //      (checked while staging; a game beyond that is done by slow_game).  Sums are int32: exact.
-//   3. "left int8" is a running max / min over the int32 results (v_max3 / v_min3); the low bytes of
-//      four results (four consecutive l) go as one dword -- unaligned for odd S, which gfx950's
-//      LDS takes -- into a dense S^3 image in LDS;
+//   3. "left int8" is a running max / min over the int32 results (v_max3 / v_min3).  The low bytes
+//      go into a dense S^3 image in LDS.  For odd S a column (S bytes) is not dword aligned and
+//      gfx950's LDS stalls on unaligned dwords (SQ_LDS_UNALIGNED_STALL was half of the kernel), so
+//      two tiles are finished together, v_permlane32_swap gives every lane one WHOLE column, and the
+//      lane writes the aligned dwords that start inside it (v_alignbyte; the dword that closes the
+//      column takes its last bytes from the next lane through DPP);
 //   4. the image goes out as aligned 16-byte chunks.
 // Built with -mllvm -amdgpu-mfma-vgpr-form: the results land in VGPRs, no v_accvgpr moves.
 // A and B fragments use the same lane -> r mapping, so the result does not depend on how the
