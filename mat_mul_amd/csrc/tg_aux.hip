@@ -129,59 +129,68 @@ __global__ __launch_bounds__(kBlock) void hash_kernel(const int8_t* state, uint6
 // N3: sum of slice ranks.  One wavefront per (game, slice i): lane r holds row r of the S x S
 // matrix state[b][i] reduced mod p; S elimination steps, each a ballot (pivot search), a broadcast
 // of the pivot row (readlane via shuffle) and a cross-multiplied update (no modular inverse):
-// row_r <- row_r * piv_c - row_p * row_r[c]  (mod p).  Run for two primes, ranks maxed.
+// row_r <- row_r * piv_c - row_p * row_r[c]  (mod p).  Two primes, one per half-wave, ranks maxed.
 // ---------------------------------------------------------------------------------------------
-// a*b mod P for P = 2^31 - C (C = 1 or 19), a, b < P: 2^31 == C (mod P), so the 62-bit product folds
-// twice by shift-multiply-add instead of a 64-bit division.
-template <uint32_t P>
-__device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) {
-  constexpr uint64_t C = (1ull << 31) - P;
-  uint64_t x = static_cast<uint64_t>(a) * b;           // < 2^62
-  x = (x & 0x7FFFFFFFull) + (x >> 31) * C;             // < 2^31 + 2^31*C
-  x = (x & 0x7FFFFFFFull) + (x >> 31) * C;             // < 2^31 + C*C
+// a*b mod P for P = 2^31 - C (C = 1 for the lower half-wave, 19 for the upper), a, b < P: 2^31 == C (mod P),
+// so the 62-bit product folds twice by shift-multiply-add instead of a 64-bit division.
+__device__ __forceinline__ uint32_t mulmod_half(uint32_t a, uint32_t b, bool upper, uint32_t P) {
+  uint64_t x = static_cast<uint64_t>(a) * b;  // < 2^62
+  uint64_t t = x >> 31;
+  x = (x & 0x7FFFFFFFull) + (upper ? (t << 4) + (t << 1) + t : t);  // < 2^31 + 2^31*C
+  t = x >> 31;
+  x = (x & 0x7FFFFFFFull) + (upper ? (t << 4) + (t << 1) + t : t);  // < 2^31 + C*C
   uint32_t r = static_cast<uint32_t>(x);
   if (r >= P) r -= P;
   return r;
 }
 
-template <int ST, uint32_t P>
-__device__ __forceinline__ int slice_rank(const int8_t* m, int S, int lane) {
+// Rank of one S x S slice modulo BOTH primes at once: lanes 0..31 eliminate mod 2^31 - 1, lanes 32..63 the
+// same matrix mod 2^31 - 19 (S <= 32 rows per half-wave); the halves choose their own pivots.  Returns the
+// larger of the two ranks (a rank mod p can only be too small).
+template <int ST>
+__device__ __forceinline__ int slice_rank2(const int8_t* m, int S, int lane) {
   constexpr int SMAX = ST ? ST : TG_MAX_S;
+  const bool upper = lane >= 32;
+  const int r0 = lane & 31;
+  const uint32_t P = upper ? 2147483629u : 2147483647u;
   uint32_t row[SMAX];
 #pragma unroll
   for (int c = 0; c < SMAX; ++c) {
-    int v = (lane < S && c < S) ? m[lane * S + c] : 0;
+    int v = (r0 < S && c < S) ? m[r0 * S + c] : 0;
     row[c] = v < 0 ? P - static_cast<uint32_t>(-v) : static_cast<uint32_t>(v);
   }
-  bool used = lane >= S;  // rows already chosen as pivots (and the idle lanes)
+  bool used = r0 >= S;  // rows already chosen as pivots (and the idle lanes)
   int rank = 0;
 #pragma unroll
   for (int c = 0; c < SMAX; ++c) {
     if (c < S) {
       const uint64_t cand = __ballot(!used && row[c] != 0);
-      if (cand) {
-        const int pr = __ffsll(static_cast<long long>(cand)) - 1;  // pivot row (wave-uniform)
+      const uint32_t mine_half = upper ? static_cast<uint32_t>(cand >> 32) : static_cast<uint32_t>(cand);
+      if (cand) {  // wave-uniform; a half without a candidate just idles through the step
+        const bool has = mine_half != 0;
+        const int pr = (upper ? 32 : 0) + (has ? __builtin_ctz(mine_half) : 0);  // this half's pivot row
         const uint32_t pc = __shfl(row[c], pr);
         const uint32_t mine = row[c];
-        const bool upd = !used && lane != pr && mine != 0;
+        const bool upd = has && !used && lane != pr && mine != 0;
         // columns < c of every unused row were zeroed by earlier pivots, and column c becomes zero
 #pragma unroll
         for (int k = c + 1; k < SMAX; ++k) {
           if (k < S) {
             const uint32_t pk = __shfl(row[k], pr);
             if (upd) {
-              const uint32_t a = mulmod<P>(row[k], pc), b = mulmod<P>(pk, mine);
+              const uint32_t a = mulmod_half(row[k], pc, upper, P), b = mulmod_half(pk, mine, upper, P);
               row[k] = a >= b ? a - b : a + P - b;
             }
           }
         }
         if (upd) row[c] = 0;
-        if (lane == pr) used = true;
-        ++rank;
+        if (has && lane == pr) used = true;
+        rank += has;
       }
     }
   }
-  return rank;
+  const int r1 = __builtin_amdgcn_readlane(rank, 0), r2 = __builtin_amdgcn_readlane(rank, 32);
+  return r1 > r2 ? r1 : r2;
 }
 
 template <int ST>
@@ -195,9 +204,7 @@ __global__ __launch_bounds__(kBlock) void rank_kernel(const int8_t* state, int32
     int acc = 0;
     for (int i = wave; i < S; i += kBlock / 64) {
       const int8_t* m = state + g * stride + i * S * S;
-      const int r1 = slice_rank<ST, 2147483647u>(m, S, lane);
-      const int r2 = slice_rank<ST, 2147483629u>(m, S, lane);
-      acc += r1 > r2 ? r1 : r2;
+      acc += slice_rank2<ST>(m, S, lane);
     }
     if (lane == 0) partial[wave] = acc;
     __syncthreads();
