@@ -334,15 +334,21 @@ __global__ __launch_bounds__(kBlock) void sample_basis_kernel(int8_t* P, int8_t*
 // Change of basis: one workgroup per game, the S^3 int32 tensor lives in LDS ([i][j][k] with the
 // k-rows padded to S+1 so that all three fibre directions are bank-conflict free) and is
 // transformed IN PLACE one mode at a time; each thread owns whole fibres.
-template <int ST>
-__global__ __launch_bounds__(kBlock) void change_basis_kernel(const int8_t* in, const int32_t* basis, int8_t* out,
+// CB threads per game.  At S = 25 the int32 tensor in LDS (65 KB) allows only two workgroups per CU, and two
+// 256-thread workgroups are two wavefronts per SIMD -- nothing to hide the LDS latency of the fibre loop behind:
+// 1024 threads there (686 -> 393 us at B = 4096), 256 for the small tensors (S^2 fibres <= 256).
+template <int ST, int CB>
+__global__ __launch_bounds__(CB) void change_basis_kernel(const int8_t* in, const int32_t* basis, int8_t* out,
                                                               uint8_t* overflow, int64_t B, int Srt, int64_t stride) {
-  extern __shared__ int X[];
+  extern __shared__ __attribute__((aligned(16))) int X[];
   const int S = ST ? ST : Srt;
   const int P = S + 1, S2 = S * S, N = S2 * S;
+  constexpr int SP = ((ST ? ST : TG_MAX_S) + 3) & ~3;  // fibre length padded to whole ds_read_b128
+  const int MP = (S + 3) & ~3;
+  int* const Ms = X + ((S2 * P + 3) & ~3);             // this mode's matrix, rows of MP ints
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     const int8_t* src = in + b * stride;
-    for (int e = threadIdx.x; e < N; e += kBlock) {
+    for (int e = threadIdx.x; e < N; e += CB) {
       const int i = e / S2, r = e - i * S2, j = r / S, k = r - j * S;
       X[(i * S + j) * P + k] = src[e];
     }
@@ -350,20 +356,46 @@ __global__ __launch_bounds__(kBlock) void change_basis_kernel(const int8_t* in, 
 #pragma unroll 1
     for (int mode = 0; mode < 3; ++mode) {
       const int32_t* M = basis + (b * 3 + mode) * S2;
+      // this mode's matrix -> LDS, rows padded to a multiple of 4 entries: the inner loop reads four entries of a
+      // row with one broadcast ds_read_b128 (the same address in every lane) instead of one scalar load per MAC
+      int mw = 0;
+      for (int e = threadIdx.x; e < S * MP; e += CB) {
+        const int a = e / MP, t = e - a * MP;
+        const int v = t < S ? M[a * S + t] : 0;
+        Ms[e] = v;
+        mw |= (v + (1 << 23)) >> 24;
+      }
+      const bool mfits = !__syncthreads_or(mw);  // every entry in [-2^23, 2^23); also: Ms is complete
       // element (f, t) of a fibre: mode 0 walks i, mode 1 walks j, mode 2 walks k
       const int step = mode == 0 ? S * P : (mode == 1 ? P : 1);
-      for (int f = threadIdx.x; f < S2; f += kBlock) {
+      for (int f = threadIdx.x; f < S2; f += CB) {
         const int p = f / S, q = f - p * S;
         const int base = mode == 0 ? p * P + q : (mode == 1 ? p * S * P + q : (p * S + q) * P);
-        int x[ST ? ST : TG_MAX_S];
+        int x[SP];
+        int wide = 0;
 #pragma unroll
-        for (int t = 0; t < (ST ? ST : TG_MAX_S); ++t)
-          if (t < S) x[t] = X[base + t * step];
+        for (int t = 0; t < SP; ++t) {
+          x[t] = t < S ? X[base + t * step] : 0;
+          wide |= (x[t] + (1 << 23)) >> 24;  // non-zero <=> x outside [-2^23, 2^23)
+        }
+        // int32 * int32 is a quarter-rate multiply; while the matrix entries and this wavefront's values fit 24
+        // bits, v_mad_i32_i24 gives the same low 32 bits at full rate
+        const bool fast = mfits && __ballot(wide != 0) == 0;
         for (int a = 0; a < S; ++a) {
+          const int4* mrow = reinterpret_cast<const int4*>(Ms + a * MP);
           int acc = 0;
 #pragma unroll
-          for (int t = 0; t < (ST ? ST : TG_MAX_S); ++t)
-            if (t < S) acc += M[a * S + t] * x[t];
+          for (int t4 = 0; t4 < SP / 4; ++t4) {
+            const int4 m4 = mrow[t4];
+            if (fast) {
+              acc = mad24_pinned(m4.x, x[4 * t4], acc);
+              acc = mad24_pinned(m4.y, x[4 * t4 + 1], acc);
+              acc = mad24_pinned(m4.z, x[4 * t4 + 2], acc);
+              acc = mad24_pinned(m4.w, x[4 * t4 + 3], acc);
+            } else {
+              acc += m4.x * x[4 * t4] + m4.y * x[4 * t4 + 1] + m4.z * x[4 * t4 + 2] + m4.w * x[4 * t4 + 3];
+            }
+          }
           X[base + a * step] = acc;
         }
       }
@@ -371,7 +403,7 @@ __global__ __launch_bounds__(kBlock) void change_basis_kernel(const int8_t* in, 
     }
     int8_t* dst = out + b * stride;
     int ovf = 0;
-    for (int e = threadIdx.x; e < N; e += kBlock) {
+    for (int e = threadIdx.x; e < N; e += CB) {
       const int i = e / S2, r = e - i * S2, j = r / S, k = r - j * S;
       const int v = X[(i * S + j) * P + k];
       ovf |= (v < -128) | (v > 127);
@@ -503,26 +535,31 @@ int tg_change_basis_i8(const int8_t* state_in, const int32_t* basis, int8_t* sta
   if (B && state_in && state_in == state_out) return tg_internal_fail(TG_ERR_INVALID, "%s: in-place is not supported", fn);
   if (B == 0) return TG_OK;
   if (!state_in || !basis || !state_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
-  const size_t lds = static_cast<size_t>(S) * S * (S + 1) * sizeof(int);
+  // int32 tensor with rows padded to S+1, then one mode's matrix with rows padded to whole 16-byte reads (+ slack
+  // for the run-time-S kernel, whose unrolled row loop may read past the last row into zero-weighted entries)
+  const size_t lds = ((static_cast<size_t>(S) * S * (S + 1) + 3) / 4 * 4 + static_cast<size_t>(S) * ((S + 3) / 4 * 4) + 32) * sizeof(int);
   if (lds > 160 * 1024) return tg_internal_fail(TG_ERR_UNSUPPORTED, "%s: S=%d needs %zu B of LDS", fn, S, lds);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(grid_for(B)), block(tg::kBlock);
-#define TG_CB(ST)                                                                                      \
+  const dim3 grid(grid_for(B));
+#define TG_CB(ST, CB)                                                                                  \
   do {                                                                                                 \
     if (lds > 64 * 1024) {                                                                             \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tg::change_basis_kernel<ST>),   \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tg::change_basis_kernel<ST, CB>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
       if (e != hipSuccess) return tg_internal_fail(TG_ERR_HIP, "%s: %s", fn, hipGetErrorString(e));    \
     }                                                                                                  \
-    (void)hipGetLastError(); hipLaunchKernelGGL(tg::change_basis_kernel<ST>, grid, block, lds, st, state_in, basis, state_out,  \
+    (void)hipGetLastError(); hipLaunchKernelGGL((tg::change_basis_kernel<ST, CB>), grid, dim3(CB), lds, st, state_in, basis, state_out,  \
                        overflow, B, S, game_stride_bytes);                                             \
   } while (0)
   switch (S) {
-    case 4: TG_CB(4); break;
-    case 9: TG_CB(9); break;
-    case 16: TG_CB(16); break;
-    case 25: TG_CB(25); break;
-    default: TG_CB(0); break;
+    case 4: TG_CB(4, 256); break;
+    case 9: TG_CB(9, 256); break;
+    case 16: TG_CB(16, 256); break;
+    case 25: TG_CB(25, 1024); break;
+    default:
+      if (S > 16) TG_CB(0, 1024);
+      else TG_CB(0, 256);
+      break;
   }
 #undef TG_CB
   return launched(fn);
