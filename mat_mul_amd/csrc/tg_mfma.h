@@ -109,38 +109,58 @@ __global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) 
   }
   const int woff = (2 * S + col) * RS + 16 * h;
 
+  // Token fetch and staging.  Buffer loads: one VGPR of lane offset + immediates instead of 24 64-bit addresses,
+  // and rows r >= R fall outside num_records (they read as 0), so no clamping.  fetch() only issues the loads of
+  // one batch (TB trips of 4 actions); commit() turns a batch into factors, checks their range and writes T.
+  auto fetch = [&](int64_t gg, int rb, int (&f)[TB][4]) {
+    const __amdgpu_buffer_rsrc_t tok = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int8_t*>(a.actions + gg * R * G::A3), 0, R * G::A3, 0x00027000);
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = rb + 4 * NRG * tb + t;
+        f[tb][t] = static_cast<int8_t>(__builtin_amdgcn_raw_buffer_load_b8(tok, sx + r * G::A3, 0, 0));
+      }
+  };
+  auto commit = [&](int rb, int (&f)[TB][4], int& big) {
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+      const int r0 = rb + 4 * NRG * tb;
+      if (r0 < Rp) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f[tb][t] = (r0 + t < R) ? f[tb][t] - a.shift : 0;
+          big |= (f[tb][t] < slo) | (f[tb][t] > shi);
+        }
+        *reinterpret_cast<uint32_t*>(T + sx * RS + r0) = pack4(f[tb][0], f[tb][1], f[tb][2], f[tb][3]);
+      }
+    }
+  };
+  // When one batch covers all the actions (R <= 4 NRG TB), the NEXT game's tokens are fetched right after this
+  // game's staging barrier and stay in registers through the tile phase: the memory latency (about a quarter of
+  // a game's time in this kernel) disappears behind the arithmetic.
+  const bool one_batch = Rp <= 4 * NRG * TB;  // uniform
+  int pf[TB][4];
+  if (one_batch && srg < NRG && static_cast<int64_t>(blockIdx.x) < a.B) fetch(blockIdx.x, 4 * srg, pf);
+
   for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
     // ---- 1. factors of this game, transposed into LDS (4 actions = one dword); range check; r >= R -> 0 ----
-    // buffer loads: one VGPR of lane offset + immediates instead of 24 64-bit addresses, and rows r >= R fall
-    // outside num_records (they read as 0), so no clamping
-    const __amdgpu_buffer_rsrc_t tok = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int8_t*>(a.actions + g * R * G::A3), 0, R * G::A3, 0x00027000);
     int big = 0;
     if (srg < NRG) {
-      for (int rb = 4 * srg; rb < Rp; rb += 4 * NRG * TB) {
-        int f[TB][4];
-#pragma unroll
-        for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int r = rb + 4 * NRG * tb + t;
-            f[tb][t] = static_cast<int8_t>(__builtin_amdgcn_raw_buffer_load_b8(tok, sx + r * G::A3, 0, 0));
-          }
-#pragma unroll
-        for (int tb = 0; tb < TB; ++tb) {
-          const int r0 = rb + 4 * NRG * tb;
-          if (r0 < Rp) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              f[tb][t] = (r0 + t < R) ? f[tb][t] - a.shift : 0;
-              big |= (f[tb][t] < slo) | (f[tb][t] > shi);
-            }
-            *reinterpret_cast<uint32_t*>(T + sx * RS + r0) = pack4(f[tb][0], f[tb][1], f[tb][2], f[tb][3]);
-          }
+      if (one_batch) {
+        commit(4 * srg, pf, big);
+      } else {
+        for (int rb = 4 * srg; rb < Rp; rb += 4 * NRG * TB) {
+          int f[TB][4];
+          fetch(g, rb, f);
+          commit(rb, f, big);
         }
       }
     }
-    if (__syncthreads_or(big)) {  // workgroup-uniform; rare: exact byte-wise form
+    const bool too_big = __syncthreads_or(big);
+    if (one_batch && srg < NRG && g + gridDim.x < a.B) fetch(g + gridDim.x, 4 * srg, pf);
+    if (too_big) {  // workgroup-uniform; rare: exact byte-wise form
       note_fallback();
       slow_game<GENF>(a, g, flags);
       __syncthreads();
