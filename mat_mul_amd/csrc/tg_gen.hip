@@ -331,6 +331,68 @@ __global__ __launch_bounds__(kBlock) void sample_basis_kernel(int8_t* P, int8_t*
   }
 }
 
+// The same on the matrix cores, one WAVEFRONT per (game, mode): the cells go into two 32 x 32 byte images in LDS,
+// L row-major and U transposed (rows and columns past S are zero), so both fragments of P = L U are one
+// ds_read_b128 per lane and the product is ONE v_mfma_i32_32x32x32_i8.  No workgroup barrier: a wavefront owns its
+// images.  Same cell -> value rule as sample_basis_kernel (the oracle's).
+__global__ __launch_bounds__(kBlock) void sample_basis_mfma_kernel(int8_t* P, int8_t* Lo, int8_t* Uo, int64_t B, int S,
+                                                                   Dist D, uint64_t seed, uint64_t gid0) {
+  __shared__ __attribute__((aligned(16))) int8_t img[kBlock / 64][2][32 * 32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int8_t* const Lb = img[wave][0];
+  int8_t* const Ut = img[wave][1];
+  const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+  const int cells = S * S, nblk = (cells + 3) >> 2;
+  const int col = lane & 31, h = lane >> 5;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (kBlock / 64);
+  for (int64_t m = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave; m < 3 * B; m += nwaves) {
+    const int64_t b = m / 3;
+    const int x = static_cast<int>(m - 3 * b);
+    const uint64_t gid = gid0 + static_cast<uint64_t>(b);
+    // both images = 2 KiB = 8 dwords per lane
+#pragma unroll
+    for (int t = 0; t < 8; ++t) reinterpret_cast<uint32_t*>(img[wave])[lane + 64 * t] = 0u;
+    for (int q = lane; q < nblk; q += 64) {
+      const U4 o = philox4x32_10(U4{static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
+                                    kStreamBasis | static_cast<uint32_t>(x), static_cast<uint32_t>(q)},
+                                 k0, k1);
+      const uint32_t d[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 4 * q + t;
+        if (c < cells) {
+          const int a = c / S, bb = c - a * S;
+          const int v = draw_value(d[t], D);
+          Lb[a * 32 + bb] = static_cast<int8_t>(a > bb ? v : (a == bb ? 1 - 2 * static_cast<int>(d[t] & 1u) : 0));
+          Ut[bb * 32 + a] = static_cast<int8_t>(a < bb ? v : (a == bb ? 1 - 2 * static_cast<int>((d[t] >> 1) & 1u) : 0));
+        }
+      }
+    }
+    // A: row a = col of L (k = 16 h ..), B: column b = col of U = row col of Ut
+    const bt_v4i fa = *reinterpret_cast<const bt_v4i*>(Lb + col * 32 + 16 * h);
+    const bt_v4i fb = *reinterpret_cast<const bt_v4i*>(Ut + col * 32 + 16 * h);
+    bt_v16i acc;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0;
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, acc, 0, 0, 0);
+    int8_t* Pm = P + m * cells;
+    if (col < S) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int a = (t & 3) + 8 * (t >> 2) + 4 * h;  // row of D in register t
+        if (a < S) Pm[a * S + col] = static_cast<int8_t>(acc[t]);
+      }
+    }
+    if (Lo || Uo) {
+      for (int c = lane; c < cells; c += 64) {
+        const int a = c / S, bb = c - a * S;
+        if (Lo) Lo[m * cells + c] = Lb[a * 32 + bb];
+        if (Uo) Uo[m * cells + c] = Ut[bb * 32 + a];
+      }
+    }
+  }
+}
+
 // Change of basis: one workgroup per game, the S^3 int32 tensor lives in LDS ([i][j][k] with the
 // k-rows padded to S+1 so that all three fibre directions are bank-conflict free) and is
 // transformed IN PLACE one mode at a time; each thread owns whole fibres.
@@ -520,9 +582,15 @@ int tg_sample_basis_i8(int8_t* basis_out, int8_t* lower_out, int8_t* upper_out, 
   if (int rc = make_dist(fn, thresholds, values, n_values, &D)) return rc;
   if (B == 0) return TG_OK;
   if (!basis_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
-  (void)hipGetLastError(); hipLaunchKernelGGL(tg::sample_basis_kernel, dim3(grid_for(3 * B)), dim3(tg::kBlock), 0,
-                     static_cast<hipStream_t>(stream), basis_out, lower_out, upper_out, B, S, D, seed,
-                     game_id_offset);
+  static const bool no_mfma = getenv("TG_NO_MFMA") != nullptr;  // A/B switch for measurements
+  (void)hipGetLastError();
+  if (!no_mfma)  // one wavefront per matrix, four per workgroup
+    hipLaunchKernelGGL(tg::sample_basis_mfma_kernel, dim3(grid_for((3 * B + 3) / 4)), dim3(tg::kBlock), 0,
+                       static_cast<hipStream_t>(stream), basis_out, lower_out, upper_out, B, S, D, seed, game_id_offset);
+  else
+    hipLaunchKernelGGL(tg::sample_basis_kernel, dim3(grid_for(3 * B)), dim3(tg::kBlock), 0,
+                       static_cast<hipStream_t>(stream), basis_out, lower_out, upper_out, B, S, D, seed,
+                       game_id_offset);
   return launched(fn);
 }
 
