@@ -227,16 +227,19 @@ __device__ __forceinline__ bt_v4i load_row_fragment(const int8_t* row, int h) { 
 }
 
 template <int S>
-__global__ __launch_bounds__(kBlock) void basis_tokens_mfma_kernel(int8_t* actions, uint8_t* overflow, int64_t B, int R,
-                                                                   int shift, const int8_t* basis) {
-  __shared__ __attribute__((aligned(16))) int rowsum[kBlock / 64][32];
+__global__ __launch_bounds__(512) void basis_tokens_mfma_kernel(int8_t* actions, uint8_t* overflow, int64_t B, int R,
+                                                                int shift, const int8_t* basis) {
+  // launched with one wavefront per job of a game when there are at most 8 (3 modes x ceil(R/32) action tiles:
+  // 6 at R = 64), so that no wavefront does two jobs while others idle
+  __shared__ __attribute__((aligned(16))) int rowsum[8][32];
+  const int nwave = static_cast<int>(blockDim.x >> 6);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
   const int ntile = (R + 31) >> 5, njob = 3 * ntile;
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     int8_t* blk = actions + b * R * 3 * S;
     int hi = 0, lo = 0;
-    for (int job = wave; job < njob; job += kBlock / 64) {
+    for (int job = wave; job < njob; job += nwave) {
       const int x = job / ntile, r0 = 32 * (job - x * ntile);
       // A: row a = col of M_x (rows >= S shadow the last one; their results are never used)
       const int8_t* mrow = basis + ((b * 3 + x) * S + (col < S ? col : S - 1)) * S;
@@ -557,7 +560,8 @@ int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, 
     const size_t lds = 3 * static_cast<size_t>(S) * S * sizeof(int) + 64 * 3 * static_cast<size_t>(S);
     const dim3 bgrid(grid_for(B > 16384 ? 16384 : B)), bblock(192);
     static const bool no_mfma = getenv("TG_NO_MFMA") != nullptr;  // A/B switch for measurements
-    const dim3 mgrid(grid_for(B > 65536 ? 65536 : B)), mblock(tg::kBlock);
+    const int mjob = 3 * ((R + 31) / 32);
+    const dim3 mgrid(grid_for(B > 65536 ? 65536 : B)), mblock(64 * (mjob < 8 ? mjob : 8));
     switch (no_mfma ? -S : S) {
       case 9: hipLaunchKernelGGL(tg::basis_tokens_mfma_kernel<9>, mgrid, mblock, 0, st, actions_out, overflow, B, R, shift, basis); break;
       case 16: hipLaunchKernelGGL(tg::basis_tokens_mfma_kernel<16>, mgrid, mblock, 0, st, actions_out, overflow, B, R, shift, basis); break;
