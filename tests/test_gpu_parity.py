@@ -293,7 +293,8 @@ def test_gen_from_factors_matrix_core_path(S, R):
     before = ops.debug_fallbacks()
     out = ops.gen_from_factors(dev(ac), S, overflow=ovf)
     assert np.array_equal(host(out), want) and np.array_equal(host(ovf), wovf)
-    if R <= 256:
+    import os
+    if R <= 256 and not os.environ.get("TG_NO_MFMA"):        # (the vector kernels have other factor limits)
         assert ops.debug_fallbacks() - before == 1           # game 2 only
     # padded game stride and a second shift
     want2, wovf2 = O.gen_from_factors_i8(ac, 2)
