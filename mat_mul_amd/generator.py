@@ -35,6 +35,16 @@ class SyntheticDemos:
             seed=seed, game_id_offset=game_id_offset, basis=basis, overflow=self.overflow)
 
     @classmethod
+    def generate(cls, n_demos: int, dim_3d: int, max_actions: int, device="cuda", dim_t: int = 1, **kw) -> "SyntheticDemos":
+        """``SyntheticDemos.generate(...)`` of SURVEY.md section 8(b): the same as the constructor, with the
+        three sizes first.  ``random_basis=True`` draws a GL(S,Z) basis per demo (``ops.sample_basis``) keyed like
+        the demos themselves and emits every demo in it (BASELINE config 5)."""
+        if kw.pop("random_basis", False):
+            kw["basis"] = ops.sample_basis(n_demos, dim_3d, device, seed=kw.get("seed", 0) ^ 0x5EED,
+                                           game_id_offset=kw.get("game_id_offset", 0))
+        return cls(max_actions, n_demos, dim_t, dim_3d, device=device, **kw)
+
+    @classmethod
     def sharded(cls, max_actions: int, n_demos_global: int, dim_t: int, dim_3d: int, rank: int, world_size: int,
                 device="cuda", **kw):
         """The demos [lo, hi) of an ``n_demos_global`` dataset owned by ``rank`` (contiguous range; the

@@ -427,6 +427,19 @@ def test_generator_distribution_vs_reference(golden):
         assert p > 1e-3, (key, ours, p)
 
 
+def test_synthetic_demos_generate_entry():
+    """SyntheticDemos.generate == the constructor; random_basis emits every demo in its own
+    GL(S,Z) basis and the demo still replays to zero."""
+    a = SyntheticDemos.generate(n_demos=5, dim_3d=9, max_actions=6, device=DEV, seed=3)
+    b = SyntheticDemos(max_actions=6, n_demos=5, dim_t=1, dim_3d=9, device=DEV, seed=3)
+    assert torch.equal(a.action_seq, b.action_seq) and torch.equal(a.target_tensor, b.target_tensor)
+    c = SyntheticDemos.generate(n_demos=5, dim_3d=9, max_actions=6, device=DEV, seed=3, random_basis=True)
+    assert not torch.equal(c.action_seq, a.action_seq)
+    final, ds = ops.step_many(c.target_tensor, c.action_seq)
+    ok = host(c.overflow) == 0
+    assert ok.any() and not host(final)[ok].any() and (host(ds)[ok] >= 0).all()
+
+
 def test_synthetic_demos_class_matches_reference_framing(golden):
     """SyntheticDemos.batch == the reference's __getitem__ arithmetic on the same tokens."""
     demos = SyntheticDemos(max_actions=6, n_demos=9, dim_t=3, dim_3d=4, device=DEV, seed=11)
