@@ -538,6 +538,27 @@ def test_sharded_env_equals_single_env():
     assert torch.equal(torch.cat(parts), full.state)
 
 
+@pytest.mark.parametrize("S,T", [(4, 1), (4, 3), (16, 2)])
+def test_env_graph_stepper_equals_eager_steps(S, T):
+    """TensorGameEnv.graph_stepper: replayed hipGraphs over a static token buffer == eager step() calls,
+    including the history ring (one graph per slot)."""
+    B, K = 37, 7
+    demos = SyntheticDemos(max_actions=K, n_demos=B, dim_t=T, dim_3d=S, device=DEV, seed=5)
+    eager = TensorGameEnv(B, S, DEV, dim_t=T)
+    graph = TensorGameEnv(B, S, DEV, dim_t=T)
+    eager.reset(demos.target_tensor)
+    graph.reset(demos.target_tensor)
+    buf = torch.empty((B, 3 * S), dtype=torch.int8, device=DEV)
+    step = graph.graph_stepper(buf)
+    for k in reversed(range(K)):
+        buf.copy_(demos.action_seq[:, k])
+        s1, d1 = step()
+        s0, d0 = eager.step(demos.action_seq[:, k].contiguous())
+        assert torch.equal(s1, s0) and torch.equal(d1, d0) and graph.head == eager.head
+        assert torch.equal(graph.model_input()[0], eager.model_input()[0])
+    assert bool(d1.all())
+
+
 def test_graph_capture_of_steps():
     """Launches go to the caller's stream, so K steps can be captured in one hipGraph."""
     S, B, R = 4, 4096, 7
