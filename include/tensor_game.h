@@ -152,9 +152,9 @@ int tg_change_basis_i8(const int8_t* state_in, const int32_t* basis, int8_t* sta
  * new head into slot (head_slot+1) mod T, so the reference's history shift (torch.cat of
  * act.py:271-274) costs no copy.  This entry emits the (B,T,S,S,S) tensor the model consumes
  * (model.py:101-122), newest frame first: out[b][f] = float(ring[b][(head_slot - f) mod T]).
- * out: float32 (out_is_f16 == 0) or float16, C-contiguous.  scalars (may be NULL): float32 (B,1)
+ * out: float32 (out_dtype == 0), float16 (1) or bfloat16 (2), C-contiguous; int8 values are exact in all three.  scalars (may be NULL): float32 (B,1)
  * filled with t_step (get_scalars, utils.py:22-37). */
-int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_is_f16, int64_t B, int S,
+int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_dtype, int64_t B, int S,
                    int T, int head_slot, float t_step, int64_t frame_stride_bytes,
                    int64_t game_stride_bytes, tg_stream_t stream);
 

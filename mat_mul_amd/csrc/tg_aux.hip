@@ -2,6 +2,7 @@
 // (N2) and the exact slice-rank reward (N3).  gfx950 only; part of libtensorgame.so.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
 
 #include "../../include/tensor_game.h"
 #include "tg_device.h"
@@ -9,6 +10,12 @@
 int tg_internal_fail(int code, const char* fmt, ...);  // tg_kernels.hip
 
 namespace tg {
+
+// float -> output element (small integers: exact in float32, float16 and bfloat16 alike)
+template <typename OutT>
+__device__ __forceinline__ OutT emit_cast(float x) { return static_cast<OutT>(x); }
+template <>
+__device__ __forceinline__ __hip_bfloat16 emit_cast<__hip_bfloat16>(float x) { return __float2bfloat16(x); }
 
 // ---------------------------------------------------------------------------------------------
 // N1: int8 history ring -> float model input.  One thread per 16 input bytes (64 or 32 output
@@ -56,14 +63,14 @@ __global__ __launch_bounds__(kBlock) void emit_frames_kernel(const int8_t* ring,
         lo = hi;
       }
 #pragma unroll
-      for (int t = 0; t < PER; ++t) v[t] = static_cast<OutT>(static_cast<float>(sbyte(w[t >> 2], t & 3)));
+      for (int t = 0; t < PER; ++t) v[t] = emit_cast<OutT>(static_cast<float>(sbyte(w[t >> 2], t & 3)));
     } else {
       const int8_t* nxt = (e0 + PER > N && bf + 1 < B * T) ? frame_ptr(bf + 1) : src;
 #pragma unroll
       for (int t = 0; t < PER; ++t) {
         const int e = e0 + t;
         const int8_t x = (q + t < total) ? (e < N ? src[e] : nxt[e - N]) : static_cast<int8_t>(0);
-        v[t] = static_cast<OutT>(static_cast<float>(x));
+        v[t] = emit_cast<OutT>(static_cast<float>(x));
       }
     }
     if (q + PER <= total) {
@@ -120,14 +127,14 @@ __global__ __launch_bounds__(kBlock) void emit_frames_fast_kernel(const int8_t* 
         lo = hi;
       }
 #pragma unroll
-      for (uint32_t t = 0; t < PER; ++t) v[t] = static_cast<OutT>(static_cast<float>(sbyte(w[t >> 2], t & 3)));
+      for (uint32_t t = 0; t < PER; ++t) v[t] = emit_cast<OutT>(static_cast<float>(sbyte(w[t >> 2], t & 3)));
     } else {  // the group straddles two frames (once per frame when N is not a multiple of PER)
       const int8_t* nxt = (bf + 1 < static_cast<uint32_t>(B) * T) ? frame_ptr(bf + 1) : src;
 #pragma unroll
       for (uint32_t t = 0; t < PER; ++t) {
         const int e = e0 + static_cast<int>(t);
         const int8_t x = (q + t < total) ? (e < N ? src[e] : nxt[e - N]) : static_cast<int8_t>(0);
-        v[t] = static_cast<OutT>(static_cast<float>(x));
+        v[t] = emit_cast<OutT>(static_cast<float>(x));
       }
     }
     if (q + PER <= total) {
@@ -301,7 +308,7 @@ int check_state(const char* fn, int64_t B, int S, int64_t stride) {
 
 extern "C" {
 
-int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_is_f16, int64_t B, int S,
+int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_dtype, int64_t B, int S,
                    int T, int head_slot, float t_step, int64_t frame_stride_bytes,
                    int64_t game_stride_bytes, tg_stream_t stream) {
   const char* fn = "tg_emit_frames";
@@ -315,7 +322,8 @@ int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_is_f16
   const int N = S * S * S;
   if (reinterpret_cast<uintptr_t>(out) & 15) return tg_internal_fail(TG_ERR_INVALID, "%s: out must be 16-byte aligned", fn);
   // dword loads need 4-byte aligned frames
-  const int per = out_is_f16 ? 8 : 4;
+  if (out_dtype < 0 || out_dtype > 2) return tg_internal_fail(TG_ERR_INVALID, "%s: out_dtype must be 0 (f32), 1 (f16) or 2 (bf16)", fn);
+  const int per = out_dtype ? 8 : 4;
   const int vec16 = (reinterpret_cast<uintptr_t>(ring) % 4) == 0 && frame_stride_bytes % 4 == 0 &&
                     game_stride_bytes % 4 == 0;
   const int64_t work = (B * T * N + per - 1) / per;
@@ -327,17 +335,24 @@ int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_is_f16
     // (the 32-bit loop variable passes `total` by at most one grid stride, 2^26 elements: no wrap)
     const uint32_t mN = static_cast<uint32_t>(((1ull << 32) + N - 1) / N);
     const uint32_t mT = T > 1 ? static_cast<uint32_t>(((1ull << 32) + T - 1) / T) : 0u;
-    if (out_is_f16)
+    if (out_dtype == 1)
       hipLaunchKernelGGL(tg::emit_frames_fast_kernel<__half>, grid, block, 0, st, ring, static_cast<__half*>(out), scalars,
                          static_cast<int>(B), N, T, head_slot, t_step, frame_stride_bytes, game_stride_bytes, mN, mT);
+    else if (out_dtype == 2)
+      hipLaunchKernelGGL(tg::emit_frames_fast_kernel<__hip_bfloat16>, grid, block, 0, st, ring,
+                         static_cast<__hip_bfloat16*>(out), scalars, static_cast<int>(B), N, T, head_slot, t_step,
+                         frame_stride_bytes, game_stride_bytes, mN, mT);
     else
       hipLaunchKernelGGL(tg::emit_frames_fast_kernel<float>, grid, block, 0, st, ring, static_cast<float*>(out), scalars,
                          static_cast<int>(B), N, T, head_slot, t_step, frame_stride_bytes, game_stride_bytes, mN, mT);
     return launched(fn);
   }
-  if (out_is_f16)
+  if (out_dtype == 1)
     hipLaunchKernelGGL(tg::emit_frames_kernel<__half>, grid, block, 0, st, ring, static_cast<__half*>(out), scalars,
                        B, N, T, head_slot, t_step, frame_stride_bytes, game_stride_bytes, vec16);
+  else if (out_dtype == 2)
+    hipLaunchKernelGGL(tg::emit_frames_kernel<__hip_bfloat16>, grid, block, 0, st, ring, static_cast<__hip_bfloat16*>(out),
+                       scalars, B, N, T, head_slot, t_step, frame_stride_bytes, game_stride_bytes, vec16);
   else
     hipLaunchKernelGGL(tg::emit_frames_kernel<float>, grid, block, 0, st, ring, static_cast<float*>(out), scalars,
                        B, N, T, head_slot, t_step, frame_stride_bytes, game_stride_bytes, vec16);

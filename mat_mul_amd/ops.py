@@ -381,8 +381,9 @@ def emit_frames(ring, head_slot: int, t_step: float = 0.0, dtype=torch.float32, 
         raise TensorGameError("emit_frames", -1, "each frame must be C-contiguous (S,S,S)")
     fs = ring.stride(1) if T > 1 else S ** 3
     gs = ring.stride(0) if B > 1 else max(ring.stride(0), (T - 1) * fs + S ** 3)
-    if dtype not in (torch.float32, torch.float16):
-        raise TensorGameError("emit_frames", -1, "dtype must be float32 or float16")
+    codes = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+    if dtype not in codes:
+        raise TensorGameError("emit_frames", -1, "dtype must be float32, float16 or bfloat16")
     dev = ring.device
     if out is None:
         out = torch.empty((B, T, S, S, S), dtype=dtype, device=dev)
@@ -392,7 +393,7 @@ def emit_frames(ring, head_slot: int, t_step: float = 0.0, dtype=torch.float32, 
         scalars = torch.empty((B, 1), dtype=torch.float32, device=dev)
     scalars = _flag(scalars, (B, 1), torch.float32, dev, "scalars")
     with torch.cuda.device(dev):
-        call("tg_emit_frames", _ptr(ring), _ptr(out), _ptr(scalars), int(dtype == torch.float16), B, S, T,
+        call("tg_emit_frames", _ptr(ring), _ptr(out), _ptr(scalars), codes[dtype], B, S, T,
              int(head_slot) % T, C.c_float(float(t_step)), fs, gs, _stream(dev))
     return out, scalars
 

@@ -594,9 +594,9 @@ def test_history_ring_and_model_input_golden(golden):
         assert np.array_equal(host(x), states[0].astype(np.float32))
         for k in range(len(acts)):
             env.step(dev(acts[k]))
-            for dt in (torch.float32, torch.float16):
+            for dt in (torch.float32, torch.float16, torch.bfloat16):
                 x, sc = env.model_input(dt)
-                assert x.dtype == dt and np.array_equal(host(x).astype(np.float32), states[k + 1].astype(np.float32)), (tag, k)
+                assert x.dtype == dt and np.array_equal(host(x.float()), states[k + 1].astype(np.float32)), (tag, k)
             assert host(sc).tolist() == [[float(k + 1)]] * B
     # fresh games: zero history (build_matmul_tensor(dim_t, ...), utils.py:157), odd sizes / unaligned frames
     env = TensorGameEnv(5, 9, DEV, dim_t=4)
@@ -607,6 +607,11 @@ def test_history_ring_and_model_input_golden(golden):
     ring = torch.randint(-5, 6, (3, 2, 5, 5, 5), dtype=torch.int8, device=DEV)  # packed 125-byte frames
     x, _ = ops.emit_frames(ring, 1, 0.0)
     assert np.array_equal(host(x), host(ring)[:, ::-1].astype(np.float32))
+    # the whole int8 range is exact in every output type (bfloat16 has 8 significant bits: |x| <= 256)
+    ring = torch.arange(-128, 128, dtype=torch.int16, device=DEV).to(torch.int8).repeat(4)[:1000].reshape(1, 1, 10, 10, 10)
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        x, _ = ops.emit_frames(ring.contiguous(), 0, 0.0, dt)
+        assert x.dtype == dt and torch.equal(x.float(), ring.float())
 
 
 def test_state_hash_matches_oracle(golden):
@@ -922,7 +927,7 @@ def test_no_out_of_bounds_writes():
         check_flat(tbuf, "gen_demos tokens")
         check(gbuf, 5, S, -(-n // 16) * 16, "gen_demos target")
         ring = ops.alloc_ring(3, S, 2, DEV)
-        for dt in (torch.float32, torch.float16):
+        for dt in (torch.float32, torch.float16, torch.bfloat16):
             xbuf, x = guarded((3, 2, S, S, S), dt)
             scbuf, sc = guarded((3, 1), torch.float32)
             if x.data_ptr() % 16 == 0:
