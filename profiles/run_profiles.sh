@@ -23,4 +23,9 @@ for wl in "4 65536" "4 4194304" "16 8192" "16 131072" "25 4096"; do
 done
 # 4. the generator of BASELINE config 5 (tokens -> change of basis -> accumulation on the matrix cores)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/generator -o generator -- python3 $R/tools/prof_basis.py > $OUT/generator.log 2> $OUT/generator.err || exit 1
+# 5. the matrix-core kernels under PMC counters (what bounds them: DESIGN.md section 3)
+for op in genf many; do
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/mfma_${op}_p1 -o pmc -- python3 $R/tools/prof_one.py --op $op --S 25 --B 4096 --R 64 --iters 5 > $OUT/mfma_${op}_p1.log 2>&1 || exit 1
+  rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/mfma_${op}_p2 -o pmc -- python3 $R/tools/prof_one.py --op $op --S 25 --B 4096 --R 64 --iters 5 > $OUT/mfma_${op}_p2.log 2>&1 || exit 1
+done
 echo profiles done

@@ -45,4 +45,21 @@ for key, e in traffic.items():
         e["algorithmic_bytes_per_launch"] = B * (2 * S ** 3 + 3 * S + 1)
         e["traffic_over_algorithmic"] = round(e["hbm_bytes_per_launch"] / e["algorithmic_bytes_per_launch"], 4)
 json.dump(traffic, open(dst / f"traffic_{tag}.json", "w"), indent=1, sort_keys=True)
+
+# PMC counters of the matrix-core kernels (S=25, B=4096, R=K=64): averages per launch
+mfma = {}
+for d in sorted(glob.glob(str(src / "mfma_*_p?"))):
+    op = Path(d).name.split("_")[1]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(Path(d) / "pmc_counter_collection.csv")):
+        n = r["Kernel_Name"]
+        if "mfma_kernel" in n and ("genf" in n) == (op == "genf"):
+            agg[(n.split("(")[0].replace("void ", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (kern, ctr), v in agg.items():
+        mfma.setdefault(kern, {})[ctr] = round(sum(v) / len(v), 1)
+for kern, e in mfma.items():
+    if "SQ_WAVES" in e and "SQ_INSTS_VALU" in e:
+        e["valu_per_wave"] = round(e["SQ_INSTS_VALU"] / e["SQ_WAVES"], 1)  # a wavefront serves several games
+        e["valu_per_game_and_wavefront"] = round(e["SQ_INSTS_VALU"] / (4096 * 4), 1)  # B = 4096, 4 wavefronts per game
+json.dump(mfma, open(dst / f"{tag}_mfma_pmc.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic, indent=1, sort_keys=True))
