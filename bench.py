@@ -1,28 +1,47 @@
 #!/usr/bin/env python3
 """bench.py -- env steps/s of the tensor-game step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--samples n] [--scaling weak|strong] [--global-batch G]
 
-A "step" is ONE launch of the hot-path kernel (tg_step_i8, in place) over the whole batch of
-games resident in HBM.  Workload at every N: BASELINE config 2 per GPU -- S=4 int8, 65 536
-independent games per GPU (weak scaling: games are sharded by contiguous global id range, no
-collective on the data path).  The K timed steps are chained (each step consumes the state the
-previous one wrote) and cycle through a 2R-action schedule that returns every game to its start
-state, so the timed region checks itself.
+A "step" is ONE launch of the hot-path kernel (tg_step_i8, in place) over the whole batch of games resident in
+HBM.  Workloads:
+  N = 1          BASELINE config 2: S=4 int8, 65 536 independent games.
+  N > 1          BASELINE config 4 by default (--scaling strong --global-batch 1048576): S=4, 2^20 games sharded
+                 over the N GPUs by contiguous global id range (131 072 per GPU at N=8); --scaling weak keeps
+                 65 536 games per GPU instead.  No collective on the data path; RCCL carries the barrier and the
+                 max-over-ranks of the elapsed time only.
+  With --gpus N > 1 and no WORLD_SIZE in the environment, bench.py starts its N ranks itself (child processes
+  under torch.distributed.run, before anything touches the GPU) and relays rank 0's JSON line and exit code.
+
+Timing: W untimed warm-up steps, then `samples` timed samples (default 9) of EXACTLY K steps each, every sample
+bracketed by a barrier + torch.cuda.synchronize() on both sides; per sample the MAX over ranks is taken, and
+`ms_per_step` / `value` are the MEDIAN sample (all samples are listed).  The K steps of a sample are chained
+(each consumes the state the previous one wrote), replayed as one hipGraph, and cycle through an action schedule
+that returns every game to its start state, so the timed region checks itself.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- algorithmic bytes per launch / average launch time (HIP events on the launch
-                  stream) against the 8 TB/s HBM peak, for the kernel the timed region runs;
-  cpu_baseline -- the oracle's reference-dtype torch-CPU port (oracle/ref_dtype_torch.py) timed
-                  on this box's host cores on a bounded sample of the same workload;
-  also         -- the same measurement on the other single-GPU BASELINE configs and on a
-                  batch large enough to stream from HBM (informational, rank 0, N=1 only).
+  roofline     -- the step kernel against the 8 TB/s HBM peak.  `avg_launch_us` is measured with HIP events on the
+                  launch stream around each of the `samples` replays of the K-launch graph, enqueued back to back
+                  (no host sync in between, so the one-off submit latency of a replay overlaps the previous one),
+                  median / K.  `achieved`/`frac` price the bytes the step NEEDS (= SURVEY's algorithmic
+                  2S^3+3S+1 per game, minus the stores of 16-byte chunks the action leaves unchanged, which the
+                  in-place S>=9 kernels skip; computed exactly from the schedule on the device);
+                  `frac_algorithmic` prices SURVEY's figure unconditionally, `frac_traffic` the PMC bytes of the
+                  committed rocprofv3 passes (profiles/traffic_rNN.json), `copy_ceiling_GBps` a copy kernel of the
+                  same footprint measured in the same run;
+  cpu_baseline -- the oracle's reference-dtype torch-CPU port (oracle/ref_dtype_torch.py) timed on this box's
+                  host cores on a bounded sample of the same workload;
+  also         -- the same measurement on the other single-GPU BASELINE configs, SURVEY 8(d)'s dense-state inputs,
+                  HBM-streaming batches, the fused step_many and the generator (rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -33,6 +52,9 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+INFINITY_CACHE_BYTES = 256 << 20
+STEP_KERNEL = {4: "tg::s4_kernel<0>", 16: "tg::s16_step_kernel<0>", 9: "tg::packed_kernel<9, 16, 0>",
+               25: "tg::packed_kernel<25, 256, 0>"}
 
 
 def bytes_step(S: int) -> int:
@@ -40,9 +62,10 @@ def bytes_step(S: int) -> int:
     return 2 * S ** 3 + 3 * S + 1
 
 
-def make_schedule(B, S, R, dev, seed, gid0):
-    """Start state + 2R token tensors: the demo's own R actions, then the same actions with u
-    negated (which add the terms back).  After R steps every game is zero; after 2R it is back."""
+# ------------------------------------------------------------------------------------------- workloads
+def make_demo_schedule(B, S, R, dev, seed, gid0):
+    """Start state + 2R token tensors: the demo's own R actions, then the same actions with u negated (which add
+    the terms back).  After R steps every game is zero; after 2R it is back at its start."""
     from mat_mul_amd import ops
 
     actions, target = ops.gen_demos(B, S, R, dev, seed=seed, game_id_offset=gid0)
@@ -53,118 +76,246 @@ def make_schedule(B, S, R, dev, seed, gid0):
         a = actions[:, k].clone()
         a[:, :S] = 2 - a[:, :S]  # token = u + 1  ->  -u + 1
         sched.append(a.contiguous())
-    return target, sched
+    return target, sched, {"terminal_after": R}
 
 
-def time_steps(B, S, K, W, dev, mode, seed=0, gid0=0, R=None, sync=None):
-    """Returns dict(wall_s, event_ms, ok).  EXACTLY K timed launches after W warm-up launches."""
+def make_dense_schedule(B, S, dev, seed):
+    """SURVEY.md section 8(d)'s inputs: state entries i.i.d. uniform on {-2..2}, tokens i.i.d. on {0,1,2} with the
+    reference's (0.15, 0.7, 0.15) weights, every 97th game set to state = action tensor so that `done` fires.
+    Schedule = (a, a with u negated): period 2, every game returns to its start."""
     from mat_mul_amd import ops
 
-    R = R or (7 if S == 4 else 8)
-    target, sched = make_schedule(B, S, R, dev, seed, gid0)
+    g = torch.Generator(device="cpu").manual_seed(seed)
     state = ops.alloc_states(B, S, dev)
-    state.copy_(target)
-    done = torch.zeros(B, dtype=torch.uint8, device=dev)
-    ovf = torch.zeros(B, dtype=torch.uint8, device=dev)
-    launch = ops.prepare_step(state, sched, done, ovf, shift=1)
-    L = len(sched)
-    pos = 0
-    for _ in range(W):
-        launch(pos % L)
-        pos += 1
-    torch.cuda.synchronize(dev)
-    start_pos = pos
+    state.copy_(torch.randint(-2, 3, (B, S, S, S), generator=g, dtype=torch.int8).to(dev))
+    probs = torch.tensor([0.15, 0.7, 0.15])
+    tok = torch.multinomial(probs, B * 3 * S, replacement=True, generator=g).to(torch.int8).reshape(B, 3 * S).to(dev)
+    planted = torch.arange(0, B, 97, device=dev)
+    state[planted] = ops.gen_from_factors(tok[planted].unsqueeze(1).contiguous(), S)
+    neg = tok.clone()
+    neg[:, :S] = 2 - neg[:, :S]
+    return state, [tok.contiguous(), neg.contiguous()], {"planted": planted}
 
-    plan = []  # (graph, replays, kernel nodes) in timed order
-    warm_replay = 0
-    if mode == "graph":
-        # Graphs hold whole 2R cycles wherever possible: such a graph is the same for every chunk (one
-        # instantiation, replayed).  Every graph is replayed once UNTIMED before the timed region, because the
-        # first replay of a hipGraph also uploads it (one-off, ~0.1 us per node), which is not part of a step.
-        CH = max(L, (2048 // L) * L)  # kernel nodes per graph
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
 
-        def capture(n):
+def changed_chunks_per_launch(S, sched):
+    """Average over the schedule of the number of 16-byte chunks (chunk c = bytes [16c, 16c+16) of a game) that an
+    action changes, i.e. that hold an element with u_i v_j w_l != 0.  Exact, computed on the device in slices."""
+    N = S ** 3
+    nchunk = -(-N // 16)
+    total = 0
+    for tok in sched:
+        B = tok.shape[0]
+        sl = max(1, (64 << 20) // (nchunk * 16))
+        for b0 in range(0, B, sl):
+            t = tok[b0:b0 + sl].to(torch.int16) - 1
+            nzu, nzv, nzw = (t[:, :S] != 0), (t[:, S:2 * S] != 0), (t[:, 2 * S:] != 0)
+            m = (nzu[:, :, None, None] & nzv[:, None, :, None] & nzw[:, None, None, :]).reshape(t.shape[0], N)
+            if nchunk * 16 != N:
+                m = torch.nn.functional.pad(m, (0, nchunk * 16 - N))
+            total += int(m.reshape(t.shape[0], nchunk, 16).any(dim=2).sum())
+    return total / len(sched)
+
+
+def needed_bytes_per_launch(B, S, sched, inplace=True):
+    """Bytes one launch must move: read state + tokens, write `done`, write the state -- except that in place the
+    S>=9 kernels do not store 16-byte chunks the action leaves unchanged (the S=4 kernel always stores)."""
+    alg = B * bytes_step(S)
+    if S == 4 or not inplace or S not in STEP_KERNEL:
+        return alg
+    return B * (S ** 3 + 3 * S + 1) + 16.0 * changed_chunks_per_launch(S, sched)
+
+
+# ------------------------------------------------------------------------------------------- timing
+class StepTimer:
+    """W warm-up launches, then `samples` samples of exactly K chained in-place tg_step_i8 launches."""
+
+    def __init__(self, state0, sched, dev, mode="graph", shift=1):
+        from mat_mul_amd import ops
+
+        self.dev, self.mode, self.sched, self.L = dev, mode, sched, len(sched)
+        B, S = state0.shape[0], state0.shape[1]
+        self.B, self.S = B, S
+        self.start = state0
+        self.state = ops.alloc_states(B, S, dev)
+        self.state.copy_(state0)
+        self.done = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self.ovf = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self.launch = ops.prepare_step(self.state, sched, self.done, self.ovf, shift=shift)
+        self.pos = 0
+        self.graphs = {}
+
+    def eager(self, n):
+        for _ in range(n):
+            self.launch(self.pos % self.L)
+            self.pos += 1
+
+    def _graph(self, phase, n):
+        """hipGraph of n chained launches starting at schedule phase `phase` (captured once per (phase, n))."""
+        key = (phase, n)
+        if key not in self.graphs:
+            cur = torch.cuda.current_stream(self.dev)
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(cur)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side):  # capture records the launches; nothing runs
                 for j in range(n):
-                    launch((start_pos + j) % L)  # every full chunk starts at the same phase
-            return g
+                    self.launch((phase + j) % self.L)
+            cur.wait_stream(side)
+            self.graphs[key] = g
+        return self.graphs[key]
 
+    def _plan(self, K):
+        """The K steps that start at the current position, as [(graph, replays, nodes)]: whole cycles of the
+        schedule in one big graph (replayed), the remainder in a per-phase graph."""
+        CH = max(self.L, (2048 // self.L) * self.L)
         nfull, rem = divmod(K, CH)
+        phase = self.pos % self.L
+        plan = []
         if nfull:
-            plan.append((capture(CH), nfull, CH))
+            plan.append((self._graph(phase, CH), nfull, CH))
         if rem:
-            plan.append((capture(rem), 1, rem))
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)  # capture does not execute: the state is still at start_pos
-        if not os.environ.get("TG_BENCH_NO_WARM_REPLAY"):
-            # every graph once, in timed order (K steps), then eager steps up to the next multiple of 2R: the
-            # schedule is cyclic, so the state is back at start_pos's point of it, for any K
-            for g, _, n in plan:
-                g.replay()
-                warm_replay += n
-            for j in range((-rem) % L):  # the full-chunk graph is whole cycles; only the remainder leaves a phase
-                launch((start_pos + rem + j) % L)
-                warm_replay += 1
-            torch.cuda.synchronize(dev)
+            plan.append((self._graph(phase, rem), 1, rem))
+        return plan
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if sync:
-        sync()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    ev0.record()
-    if mode == "graph":
-        for g, reps, _ in plan:
-            for _ in range(reps):
-                g.replay()
-    else:
-        for k in range(K):
-            launch((start_pos + k) % L)
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0  # this rank's K steps; the caller takes the MAX over ranks
-    if sync:
-        sync()
-    pos = start_pos + K
-    # self-check of the timed region: finish the current 2R cycle and compare with the start state
-    while pos % L:
-        launch(pos % L)
-        pos += 1
-    torch.cuda.synchronize(dev)
-    ok = bool(torch.equal(state, target)) and not bool(ovf.any())
-    return {"wall_s": wall, "event_ms": ev0.elapsed_time(ev1), "ok": ok, "warm_replay": warm_replay}
+    def run_k(self, K):
+        """Enqueue exactly K steps (no sync)."""
+        if self.mode == "graph":
+            for g, reps, _ in self._plan(K):
+                for _ in range(reps):
+                    g.replay()
+            self.pos += K
+        else:
+            self.eager(K)
+
+    def finish_cycle(self):
+        while self.pos % self.L:
+            self.eager(1)
+
+    def check(self):
+        """Self-check: finish the current cycle of the schedule and compare with the start state."""
+        self.finish_cycle()
+        torch.cuda.synchronize(self.dev)
+        return bool(torch.equal(self.state, self.start)) and not bool(self.ovf.any())
+
+    def _rewind(self, p0):
+        """Eager steps until the schedule is back at phase p0 with the state at its start-of-cycle value."""
+        self.finish_cycle()
+        while self.pos % self.L != p0 % self.L:
+            self.eager(1)
+
+    def measure(self, K, W, samples, sync=None):
+        """Returns dict(wall_s=[...], event_ms=[...], ok).  Wall samples are sync-bracketed; event samples come
+        from a second pass with the replays enqueued back to back."""
+        self.eager(W)
+        torch.cuda.synchronize(self.dev)
+        p0 = self.pos
+        # rehearsal (untimed): the same sequence of K-step runs once, so that every graph the timed passes use is
+        # captured, instantiated and uploaded (the first replay of a hipGraph uploads it); then back to phase p0
+        for _ in range(samples + 1):
+            self.run_k(K)
+        self._rewind(p0)
+        torch.cuda.synchronize(self.dev)
+        walls = []
+        for _ in range(samples):
+            if sync:
+                sync()
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            self.run_k(K)
+            torch.cuda.synchronize(self.dev)
+            walls.append(time.perf_counter() - t0)
+        if sync:
+            sync()
+        self._rewind(p0)
+        torch.cuda.synchronize(self.dev)
+        # kernel time: HIP events on the launch stream around each K-step run, no host sync between samples
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(samples + 1)]
+        self.run_k(K)  # lead-in run: the first timed sample then starts behind work already in flight
+        for i in range(samples + 1):
+            evs[i].record()
+            if i < samples:
+                self.run_k(K)
+        torch.cuda.synchronize(self.dev)
+        event_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(samples)]
+        return {"wall_s": walls, "event_ms": event_ms, "ok": self.check()}
 
 
-def measured_traffic(B, S):
-    """HBM bytes per launch of this workload from the committed rocprofv3 PMC passes
-    (profiles/traffic_r*.json, written by profiles/summarize.py), newest round first; else None."""
+def copy_ceiling_gbps(B, S, dev, K=64, samples=5):
+    """A copy kernel of the same footprint in the same run: K chained tg_copy_i8 launches (ping-pong between two
+    state buffers) replayed as a hipGraph; GB/s = 2 * S^3 * B bytes per launch / median launch time."""
+    from mat_mul_amd import ops
+
+    a, b = ops.alloc_states(B, S, dev), ops.alloc_states(B, S, dev)
+    ops.copy_states(a, b)
+    cur = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(cur)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for j in range(K):
+            ops.copy_states(a if j % 2 == 0 else b, b if j % 2 == 0 else a)
+    cur.wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize(dev)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(samples + 1)]
+    g.replay()
+    for i in range(samples + 1):
+        evs[i].record()
+        if i < samples:
+            g.replay()
+    torch.cuda.synchronize(dev)
+    us = statistics.median(evs[i].elapsed_time(evs[i + 1]) for i in range(samples)) * 1e3 / K
+    return round(2 * S ** 3 * B / (us * 1e-6) / 1e9, 1), round(us, 3)
+
+
+def measured_traffic(B, S, kernel):
+    """HBM bytes per launch of this workload from the committed rocprofv3 PMC passes (profiles/traffic_rNN.json,
+    written by profiles/summarize.py), newest round first.  Returned only when the kernel recorded there is the
+    kernel the bench runs now: a stale entry (kernel renamed or replaced) is omitted, not quoted."""
     for f in sorted((ROOT / "profiles").glob("traffic_r*.json"), reverse=True):
         try:
             e = json.loads(f.read_text()).get(f"S{S}_B{B}")
         except (OSError, ValueError):
             continue
         if e and "hbm_bytes_per_launch" in e:
-            return e["hbm_bytes_per_launch"], f.name
+            rec = e.get("kernel", "").replace(" ", "")
+            if kernel and rec.startswith(kernel.replace(" ", "")):
+                return e["hbm_bytes_per_launch"], f.stem.split("_")[-1]
+            return None, None
     return None, None
 
 
-def roofline(B, S, K, event_ms):
-    per_launch_s = event_ms * 1e-3 / K
-    achieved = B * bytes_step(S) / per_launch_s / 1e9
-    traffic, src = measured_traffic(B, S)
-    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
-            "kernel": {4: "tg::s4_kernel<STEP>", 16: "tg::s16_step_kernel<STEP>", 9: "tg::packed_kernel<9,16,STEP>",
-                       25: "tg::packed_kernel<25,256,STEP>"}.get(S, "tg::slow_kernel<STEP>"),
-            "bytes_per_launch": B * bytes_step(S), "avg_launch_us": round(per_launch_s * 1e6, 3),
-            "note": ("achieved/frac price the ALGORITHMIC bytes 2S^3+3S+1 per step; in-place steps of the S>=9 kernels "
-                     "skip the store of 16-byte chunks an action leaves unchanged, so `traffic` (PMC) can be lower")
-            if S != 4 else "achieved/frac price the algorithmic bytes 2S^3+3S+1 per step"}
+def roofline(B, S, K, event_ms_samples, needed_bytes=None, copy=None, footprint=None):
+    """The roofline object of one workload.  `frac` = needed bytes / median launch time / HBM peak: the bytes the
+    launch must move (never more than SURVEY's algorithmic figure), so it cannot be inflated by stores the kernel
+    skips; `frac_algorithmic` prices SURVEY's 2S^3+3S+1 unconditionally and CAN exceed what the memory system
+    moved; `frac_traffic` prices the PMC-measured bytes."""
+    per_launch_s = statistics.median(event_ms_samples) * 1e-3 / K
+    alg = B * bytes_step(S)
+    need = alg if needed_bytes is None else min(float(needed_bytes), float(alg))
+    kernel = STEP_KERNEL.get(S, "tg::slow_kernel<0>")
+    traffic, tround = measured_traffic(B, S, kernel)
+    footprint = footprint if footprint is not None else B * (-(-S ** 3 // 16) * 16)
+    out = {"bound": "hbm", "achieved": round(need / per_launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(need / per_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+           "frac_algorithmic": round(alg / per_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+           "frac_traffic": round(traffic / per_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+           "traffic": traffic, "traffic_round": tround, "kernel": kernel,
+           "bytes_per_launch": alg, "needed_bytes_per_launch": int(round(need)),
+           "avg_launch_us": round(per_launch_s * 1e6, 3),
+           "launch_us_samples": [round(x * 1e3 / K, 3) for x in event_ms_samples],
+           "regime": ("cache-resident: %.0f MiB of states < 256 MiB Infinity Cache, HBM itself is not exercised"
+                      % (footprint / 2 ** 20)) if footprint < INFINITY_CACHE_BYTES
+           else "hbm-streaming: %.0f MiB of states per launch" % (footprint / 2 ** 20),
+           "method": "median over the samples of (HIP events around one replay of the K-launch hipGraph, replays "
+                     "enqueued back to back) / K; frac = needed bytes per launch / that time / peak"}
+    if copy is not None:
+        out["copy_ceiling_GBps"], out["copy_launch_us"] = copy
+        out["frac_of_copy_ceiling"] = round(out["achieved"] / copy[0], 4) if copy[0] else None
+    return out
 
 
+# ------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(B, S, budget_s=12.0):
     """The reference-dtype torch-CPU port on this host: fp32 (B,1,S,S,S) state, int64 tokens.
     torch's intra-op pool is tried at a few sizes (a 256-thread pool thrashes on these small
@@ -229,26 +380,83 @@ def cpu_baseline(B, S, budget_s=12.0):
             "host_cpus_available": avail, "per_game_loop_steps_per_s": round(single, 1)}
 
 
-def main():
+# ------------------------------------------------------------------------------------------- N > 1 launch
+def self_launch(n_gpus: int, argv) -> int:
+    """--gpus N > 1 without a launcher: start the N ranks as child processes (torch.distributed.run, one rank
+    per GPU, rendezvous on 127.0.0.1) BEFORE this process has touched the GPU, relay their output, return their
+    exit code.  Never re-executes a process that has initialised HIP."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2016)
     ap.add_argument("--warmup", type=int, default=224)
+    ap.add_argument("--samples", type=int, default=9, help="timed samples of exactly --steps steps each (median reported)")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
-                    help="graph: the K launches are captured in hipGraphs and replayed; eager: K ctypes launches")
-    ap.add_argument("--dim", type=int, default=4, help="S of the timed workload (4 = BASELINE config 2)")
+                    help="graph: the K launches of a sample are one hipGraph replay; eager: K ctypes launches")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N>1: strong = --global-batch games in total (default: BASELINE config 4), weak = --batch per GPU")
+    ap.add_argument("--global-batch", type=int, default=1 << 20, help="games in total under --scaling strong")
+    ap.add_argument("--dim", type=int, default=4, help="S of the timed workload (4 = BASELINE config 2 / 4)")
     ap.add_argument("--batch", type=int, default=0, help="games per GPU (default: 65536 for S=4, 8192 for S=16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous, shard arithmetic and the JSON line only -- no GPU work (CPU test of the N>1 path)")
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, argv)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.samples < 1 or args.steps < 1:
+        raise SystemExit("--samples and --steps must be >= 1")
+
+    from mat_mul_amd import shard_range
+    from mat_mul_amd.sharding import RankGroup
+
+    S = args.dim
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    per_gpu_default = {4: 65536, 16: 8192, 25: 4096, 9: 32768}.get(S, 4096)
+    if scaling == "strong" and world > 1:
+        G = args.global_batch
+    else:
+        G = (args.batch or per_gpu_default) * world
+    lo, hi = shard_range(G, rank, world)  # contiguous global game ids of this rank
+    B = hi - lo
+    if scaling == "strong" and world > 1:
+        cfg = f"BASELINE config 4: S={S} int8, {G} games in total sharded over {world} GPUs ({G // world} per GPU)"
+    else:
+        cfg = (f"BASELINE config {2 if S == 4 else 3 if S == 16 else '-'}: S={S} int8, batch={G // world} independent "
+               f"games per GPU")
+
+    if args.dry_run:
+        group = RankGroup("gloo")
+        group.barrier()
+        (tot,) = group.max_over_ranks(float(hi))
+        if rank == 0:
+            print(json.dumps({"metric": "env steps/sec (batched games)", "value": None, "unit": "steps/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "samples": args.samples, "scaling": scaling,
+                              "dry_run": True, "config": {"workload": cfg, "S": S, "global_batch": G,
+                                                          "batch_rank0": B, "last_game_id": int(tot)}}), flush=True)
+        group.close()
+        return 0
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     # One process per GPU.  LOCAL_RANK is taken modulo the VISIBLE devices, which is the identity on a full
@@ -258,8 +466,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from mat_mul_amd import build as tg_build, shard_range
-    from mat_mul_amd.sharding import RankGroup
+    from mat_mul_amd import build as tg_build
 
     group = RankGroup(os.environ.get("TG_BENCH_BACKEND", "nccl"), dev)  # control plane only: barrier + max of the elapsed time
     if group.rank == 0 and tg_build.is_stale():  # normally built by __graft_entry__.build(); self-heal on a fresh tree
@@ -267,119 +474,156 @@ def main():
     group.barrier()
     from mat_mul_amd import _lib  # noqa: F401  (raises if libtensorgame.so or a symbol is missing: no CPU path)
 
-    S = args.dim
-    Bg = args.batch or {4: 65536, 16: 8192, 25: 4096, 9: 32768}.get(S, 4096)
-    lo, hi = shard_range(Bg * world, rank, world)  # weak scaling: Bg games per GPU
-    B = hi - lo
-
-    res = time_steps(B, S, args.steps, args.warmup, dev, args.mode, seed=0, gid0=lo, sync=group.barrier)
-    wall, bad = group.max_over_ranks(res["wall_s"], 0.0 if res["ok"] else 1.0)
+    R = 7 if S == 4 else 8
+    start, sched, _ = make_demo_schedule(B, S, R, dev, 0, lo)
+    tm = StepTimer(start, sched, dev, args.mode)
+    res = tm.measure(args.steps, args.warmup, args.samples, sync=group.barrier)
+    reduced = group.max_over_ranks(*res["wall_s"], 0.0 if res["ok"] else 1.0)
+    walls, bad = list(reduced[:-1]), reduced[-1]
     if bad:
         raise SystemExit("bench self-check failed: the state did not return to its start after full cycles")
 
     if rank == 0:
-        total_steps = Bg * world * args.steps
+        wall = statistics.median(walls)
+        need = needed_bytes_per_launch(B, S, sched)
+        copy = copy_ceiling_gbps(B, S, dev)
         out = {
-            "metric": "env steps/sec (batched games)", "value": round(total_steps / wall, 1), "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak",
+            "metric": "env steps/sec (batched games)", "value": round(G * args.steps / wall, 1), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "samples": args.samples,
+            "ms_per_step": round(wall * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "i8", "data": "synthetic",
-            "config": {"workload": f"S={S} int8, batch={Bg} independent games per GPU, one in-place tg_step_i8 "
-                                   f"launch per step (BASELINE config {2 if S == 4 else 3})",
-                       "S": S, "batch_per_gpu": Bg, "global_batch": Bg * world, "launch": args.mode,
+            "config": {"workload": cfg + "; one in-place tg_step_i8 launch per step",
+                       "S": S, "batch_per_gpu": G // world, "global_batch": G, "launch": args.mode,
                        "parallelism": f"shard{world} (contiguous game ranges, no collective)",
-                       "untimed_graph_warm_replay_steps": res["warm_replay"]},
-            "roofline": roofline(B, S, args.steps, res["event_ms"]),
+                       "timing": f"{args.samples} samples of exactly {args.steps} steps, each bracketed by barrier + "
+                                 f"synchronize, max over ranks per sample, median over samples",
+                       "wall_us_per_sample": [round(w * 1e6, 1) for w in walls]},
+            "roofline": roofline(B, S, args.steps, res["event_ms"], need, copy),
         }
+        if world > 1 and scaling == "strong" and not args.no_also:
+            # the same GLOBAL batch on ONE GPU (rank 0 alone, after the timed region): the denominator of the
+            # strong-scaling speedup, measured in the same run
+            s1, sc1, _ = make_demo_schedule(G, S, R, dev, 0, 0)
+            t1 = StepTimer(s1, sc1, dev, args.mode)
+            k1 = max(14, min(args.steps, 112))
+            r1 = t1.measure(k1, 14, 5)
+            w1 = statistics.median(r1["wall_s"])
+            out["single_gpu_same_global_batch"] = {
+                "ok": r1["ok"], "value": round(G * k1 / w1, 1), "unit": "steps/s", "steps": k1,
+                "roofline": roofline(G, S, k1, r1["event_ms"], needed_bytes_per_launch(G, S, sc1))}
+            del t1, s1, sc1
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(Bg, S)
+            out["cpu_baseline"] = cpu_baseline(G, S)
         if world == 1 and not args.no_also:
-            also = []
-            for (s2, b2, k2, label) in [(16, 8192, 512, "BASELINE config 3"), (4, 1 << 17, 1008, "BASELINE config 4 per-GPU share at 8 GPUs"),
-                                        (4, 1 << 22, 112, "HBM-streaming batch (268 MB of states)"),
-                                        (25, 4096, 208, "config 5 per-GPU step"), (16, 1 << 17, 64, "HBM-streaming batch (537 MB of states)")]:
-                if s2 == S and b2 == Bg:
-                    continue
-                r2 = time_steps(b2, s2, k2, 32, dev, args.mode, seed=1)
-                also.append({"workload": f"S={s2} batch={b2} ({label})", "ok": r2["ok"],
-                             "value": round(b2 * k2 / r2["wall_s"], 1), "unit": "steps/s",
-                             "roofline": roofline(b2, s2, k2, r2["event_ms"])})
-            from mat_mul_amd import ops
-            # the fused path, labelled separately: K actions per launch, state stays on chip
-            for (s2, b2, k2) in [(4, 65536, 7), (16, 8192, 20), (25, 4096, 64)]:
-                tok, tgt = ops.gen_demos(b2, s2, k2, dev, seed=2)
-                st2 = ops.alloc_states(b2, s2, dev)
-                ds = torch.zeros(b2, dtype=torch.int32, device=dev)
-                for _ in range(5):
-                    ops.step_many(tgt, tok, out=st2, done_step=ds)
-                reps = 50
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                fg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(fg, stream=side):  # the launches only: no Python between them
-                    for _ in range(reps):
-                        ops.step_many(tgt, tok, out=st2, done_step=ds)
-                torch.cuda.current_stream(dev).wait_stream(side)
-                fg.replay()
-                torch.cuda.synchronize(dev)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                fg.replay()
-                e1.record()
-                torch.cuda.synchronize(dev)
-                sec = e0.elapsed_time(e1) * 1e-3 / reps
-                nbytes = b2 * (2 * s2 ** 3 + k2 * 3 * s2 + 4)
-                also.append({"workload": f"FUSED tg_step_many_i8: S={s2} batch={b2}, K={k2} actions per launch "
-                                         f"(bytes per step = (2S^3 + K*3S + 4)/K; not the single-step metric)",
-                             # every game ends at zero; a few get there early when the remaining terms cancel
-                             "ok": bool(((ds >= 0) & (ds < k2)).all()) and not bool(st2.any()),
-                             "value": round(b2 * k2 / sec, 1), "unit": "steps/s",
-                             "us_per_launch": round(sec * 1e6, 2), "GBps": round(nbytes / sec / 1e9, 1)})
-            # BASELINE config 5's generator (per-GPU share: 4 096 demos, S=25, R=64), with and without the change
-            # of basis; bytes = tokens written and re-read + target written; replayed as a hipGraph
-            for with_basis in (False, True):
-                s2, b2, r2 = 25, 4096, 64
-                P = ops.sample_basis(b2, s2, dev, seed=11) if with_basis else None
-                tok = torch.empty((b2, r2, 3 * s2), dtype=torch.int8, device=dev)
-                tgt = ops.alloc_states(b2, s2, dev)
-                ovf = torch.zeros(b2, dtype=torch.uint8, device=dev)
-                for _ in range(3):
-                    ops.gen_demos(b2, s2, r2, dev, seed=7, basis=P, target=tgt, actions=tok, overflow=ovf)
-                reps = 20
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                gg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gg, stream=side):
-                    for _ in range(reps):
-                        ops.gen_demos(b2, s2, r2, dev, seed=7, basis=P, target=tgt, actions=tok, overflow=ovf)
-                torch.cuda.current_stream(dev).wait_stream(side)
-                gg.replay()
-                torch.cuda.synchronize(dev)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                gg.replay()
-                e1.record()
-                torch.cuda.synchronize(dev)
-                sec = e0.elapsed_time(e1) * 1e-3 / reps
-                # self-check: replaying the demo's own actions must bring every target to zero
-                _, dstep = ops.step_many(tgt, tok)
-                nbytes = b2 * (s2 ** 3 + 2 * 3 * s2 * r2)
-                also.append({"workload": f"GENERATOR tg_gen_demos_i8: S={s2} R={r2}, {b2} demos per launch"
-                                         f"{' in a random GL(S,Z) basis' if with_basis else ''} (BASELINE config 5 per GPU)",
-                             "ok": bool((dstep >= 0).all()) and (with_basis or not bool(ovf.any())),
-                             "value": round(b2 / sec, 1), "unit": "demos/s", "us_per_launch": round(sec * 1e6, 2),
-                             "GBps": round(nbytes / sec / 1e9, 1), "hbm_frac": round(nbytes / sec / 1e9 / 8000.0, 4),
-                             "TMACps": round(b2 * r2 * s2 ** 3 / sec / 1e12, 2)})
-            out["also"] = also
+            out["also"] = also_lines(S, G, dev, args.mode)
             # BASELINE's metric names S=4 and S=16: surface config 3 at the top level as well
-            for a3 in also:
-                if a3["workload"].startswith("S=16 batch=8192"):
+            for a3 in out["also"]:
+                if a3["workload"].startswith("S=16 batch=8192 (BASELINE config 3)"):
                     out["value_s16"] = a3["value"]
                     out["ms_per_step_s16"] = round(a3["roofline"]["avg_launch_us"] * 1e-3, 6)
                     out["roofline_s16"] = a3["roofline"]
         print(json.dumps(out), flush=True)
+    group.barrier()
     group.close()
+    return 0
+
+
+def also_lines(S_main, B_main, dev, mode):
+    """The other single-GPU workloads (informational; every line carries its own self-check)."""
+    from mat_mul_amd import ops
+
+    also = []
+    for (s2, b2, k2, label, kind) in [
+            (16, 8192, 512, "BASELINE config 3", "demo"),
+            (4, 65536, 1008, "SURVEY 8(d) dense inputs: uniform {-2..2} states, every 97th game terminal", "dense"),
+            (16, 8192, 512, "SURVEY 8(d) dense inputs: uniform {-2..2} states, every 97th game terminal", "dense"),
+            (4, 1 << 17, 1008, "BASELINE config 4 per-GPU share at 8 GPUs", "demo"),
+            (4, 1 << 20, 112, "BASELINE config 4 on ONE GPU (67 MB of states)", "demo"),
+            (4, 1 << 22, 112, "HBM-streaming batch (268 MB of states)", "demo"),
+            (25, 4096, 208, "config 5 per-GPU step", "demo"),
+            (16, 1 << 17, 64, "HBM-streaming batch (537 MB of states)", "demo")]:
+        if kind == "demo" and s2 == S_main and b2 == B_main:
+            continue
+        if kind == "demo":
+            st, sc, info = make_demo_schedule(b2, s2, 7 if s2 == 4 else 8, dev, 1, 0)
+        else:
+            st, sc, info = make_dense_schedule(b2, s2, dev, 5)
+        tm = StepTimer(st, sc, dev, mode)
+        extra_ok = True
+        if kind == "dense":  # `done` fires exactly on the planted games after the first action
+            tm.eager(1)
+            torch.cuda.synchronize(dev)
+            want = torch.zeros(b2, dtype=torch.uint8, device=dev)
+            want[info["planted"]] = 1
+            extra_ok = bool(torch.equal(tm.done, want))
+            tm.eager(1)
+        r2 = tm.measure(k2, 32, 5)
+        w2 = statistics.median(r2["wall_s"])
+        also.append({"workload": f"S={s2} batch={b2} ({label})", "ok": r2["ok"] and extra_ok,
+                     "value": round(b2 * k2 / w2, 1), "unit": "steps/s", "steps": k2,
+                     "roofline": roofline(b2, s2, k2, r2["event_ms"], needed_bytes_per_launch(b2, s2, sc),
+                                          copy_ceiling_gbps(b2, s2, dev, K=16 if b2 * s2 ** 3 > (1 << 27) else 64))})
+        del tm, st, sc
+    # the fused path, labelled separately (SURVEY 8d): K actions per launch, state stays on chip
+    for (s2, b2, k2) in [(4, 65536, 7), (16, 8192, 20), (25, 4096, 64)]:
+        tok, tgt = ops.gen_demos(b2, s2, k2, dev, seed=2)
+        st2 = ops.alloc_states(b2, s2, dev)
+        ds = torch.zeros(b2, dtype=torch.int32, device=dev)
+        sec = graph_time(lambda: ops.step_many(tgt, tok, out=st2, done_step=ds), dev, reps=50)
+        nbytes = b2 * (2 * s2 ** 3 + k2 * 3 * s2 + 4)
+        also.append({"workload": f"FUSED tg_step_many_i8: S={s2} batch={b2}, K={k2} actions per launch "
+                                 f"(bytes per step = (2S^3 + K*3S + 4)/K; not the single-step metric)",
+                     # every game ends at zero; a few get there early when the remaining terms cancel
+                     "ok": bool(((ds >= 0) & (ds < k2)).all()) and not bool(st2.any()),
+                     "value": round(b2 * k2 / sec, 1), "unit": "steps/s",
+                     "us_per_launch": round(sec * 1e6, 2), "GBps": round(nbytes / sec / 1e9, 1)})
+    # BASELINE config 5's generator (per-GPU share: 4 096 demos, S=25, R=64), with and without the change
+    # of basis; bytes = target + tokens written (SURVEY 8d: S^3 + 3SR per demo); replayed as a hipGraph
+    for with_basis in (False, True):
+        s2, b2, r2 = 25, 4096, 64
+        P = ops.sample_basis(b2, s2, dev, seed=11) if with_basis else None
+        tok = torch.empty((b2, r2, 3 * s2), dtype=torch.int8, device=dev)
+        tgt = ops.alloc_states(b2, s2, dev)
+        ovf = torch.zeros(b2, dtype=torch.uint8, device=dev)
+        sec = graph_time(lambda: ops.gen_demos(b2, s2, r2, dev, seed=7, basis=P, target=tgt, actions=tok, overflow=ovf),
+                         dev, reps=20)
+        # self-check: replaying the demo's own actions must bring every target to zero
+        _, dstep = ops.step_many(tgt, tok)
+        nbytes = b2 * (s2 ** 3 + 3 * s2 * r2)
+        also.append({"workload": f"GENERATOR tg_gen_demos_i8: S={s2} R={r2}, {b2} demos per launch"
+                                 f"{' in a random GL(S,Z) basis' if with_basis else ''} (BASELINE config 5 per GPU)",
+                     "ok": bool((dstep >= 0).all()) and (with_basis or not bool(ovf.any())),
+                     "value": round(b2 / sec, 1), "unit": "demos/s", "us_per_launch": round(sec * 1e6, 2),
+                     "GBps": round(nbytes / sec / 1e9, 1), "hbm_frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+                     "TMACps": round(b2 * r2 * s2 ** 3 / sec / 1e12, 2),
+                     "int8_mfma_frac": round(2 * b2 * r2 * s2 ** 3 / sec / 5.0e15, 4)})
+    return also
+
+
+def graph_time(fn, dev, reps, samples=5):
+    """Seconds per call of `fn` (one or more launches on the current stream): `reps` calls captured in a hipGraph,
+    replayed back to back, median over `samples` of (HIP events around one replay) / reps."""
+    for _ in range(3):
+        fn()
+    cur = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(cur)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):  # the launches only: no Python between them
+        for _ in range(reps):
+            fn()
+    cur.wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize(dev)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(samples + 1)]
+    g.replay()
+    for i in range(samples + 1):
+        evs[i].record()
+        if i < samples:
+            g.replay()
+    torch.cuda.synchronize(dev)
+    return statistics.median(evs[i].elapsed_time(evs[i + 1]) for i in range(samples)) * 1e-3 / reps
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

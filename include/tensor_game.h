@@ -10,8 +10,12 @@
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer (HIP, gfx950) unless the
  *     parameter is documented "host";
  *   - asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*, NULL = the
- *     null stream); the caller synchronises.  No allocation, no host sync, no global mutable
- *     state inside a call -- every call may be captured into a hipGraph;
+ *     null stream); the caller synchronises.  No allocation and no host sync inside a call -- every
+ *     call may be captured into a hipGraph (tg_debug_fallbacks excepted).  Thread-safe for
+ *     concurrent callers: the library reads no environment variable and keeps no mutable host state
+ *     besides per-device caches of device constants (CU count, workgroups per CU of a kernel), which
+ *     are relaxed atomics -- two threads racing on a cold entry store the same value -- and a
+ *     thread-local error string;
  *   - return 0 on success, a negative TG_ERR_* otherwise; tg_last_error() returns a thread-local
  *     message for the last failing call on this thread.  No exception crosses the boundary;
  *   - states are int8, C-contiguous (S,S,S) per game, game b at `base + b*game_stride_bytes`
@@ -63,7 +67,10 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
                uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes, int shift,
                tg_stream_t stream);
 
-/* The same step, IN PLACE, for a caller that carries the number of non-zero entries of every game:
+#ifdef TG_AB_SWITCHES
+/* A/B BUILD ONLY (libtensorgame_ab.so, -DTG_AB_SWITCHES; not part of the product library): measured slower
+ * than tg_step_i8 on MI355X and kept as a measurement reference.
+ * The same step, IN PLACE, for a caller that carries the number of non-zero entries of every game:
  * nnz (int32 (B), in/out) must hold the exact count on entry and holds it on return (the rank bound
  * of training.py:266, free of charge); done[b] = (nnz[b] == 0).  With the count at hand a kernel need
  * not read the whole state: chunks that the action does not touch are neither loaded nor stored.
@@ -73,6 +80,7 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
 int tg_step_sparse_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_t* done,
                       uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes, int shift,
                       tg_stream_t stream);
+#endif
 
 /* K sequential steps with the state resident on chip.  actions: int8 (B,K,3S).
  * done_step[b] (int32) = first step index whose post-state is all zero, or -1.
@@ -93,6 +101,13 @@ int tg_expand_i8(const int8_t* state_in, int8_t* state_out, const int8_t* action
  * Replaces tensor_factorized (utils.py:181-188) per game and the nnz bound of training.py:266. */
 int tg_done_i8(const int8_t* state, uint8_t* done, int32_t* nnz, int64_t B, int S,
                int64_t game_stride_bytes, tg_stream_t stream);
+
+/* state_out[b] = state_in[b] (the padding between games is neither read nor written).  The reference's
+ * step is functional -- get_child_states returns fresh tensors (act.py:266-275) and callers keep the
+ * parent (act.py:183-195) -- so an in-place env needs a snapshot/clone of a batch of states; also the
+ * measured device-copy ceiling bench.py reports beside the step. */
+int tg_copy_i8(const int8_t* state_in, int8_t* state_out, int64_t B, int S, int64_t in_stride_bytes,
+               int64_t out_stride_bytes, tg_stream_t stream);
 
 /* ---- reset -------------------------------------------------------------------------------- */
 

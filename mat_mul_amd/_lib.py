@@ -3,9 +3,13 @@ library is missing or an entry point is absent, importing this module raises."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "lib" / "libtensorgame.so"
+# TG_LIB_VARIANT=ab selects the A/B build (libtensorgame_ab.so, -DTG_AB_SWITCHES: the TG_* environment
+# switches, the first-generation kernels and tg_step_sparse_i8) -- measurement and A/B tests only.
+AB_VARIANT = os.environ.get("TG_LIB_VARIANT", "") == "ab"
+LIB_PATH = Path(__file__).resolve().parent / "lib" / ("libtensorgame_ab.so" if AB_VARIANT else "libtensorgame.so")
 
 TG_ABI_VERSION = 1
 TG_MAX_S = 32
@@ -29,9 +33,9 @@ SIGNATURES = {
     "tg_last_error": [],
     "tg_debug_fallbacks": [_p],
     "tg_step_i8": [_p, _p, _p, _p, _p, _i64, _i, _i64, _i, _p],
-    "tg_step_sparse_i8": [_p, _p, _p, _p, _p, _i64, _i, _i64, _i, _p],
     "tg_step_many_i8": [_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _p],
     "tg_expand_i8": [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i, _p],
+    "tg_copy_i8": [_p, _p, _i64, _i, _i64, _i64, _p],
     "tg_done_i8": [_p, _p, _p, _i64, _i, _i64, _p],
     "tg_reset_matmul_i8": [_p, _i64, _i, _i64, _p],
     "tg_reset_broadcast_i8": [_p, _p, _i64, _i, _i64, _p],
@@ -43,6 +47,8 @@ SIGNATURES = {
     "tg_hash_u64": [_p, _p, _i64, _i, _i64, _p],
     "tg_rank_i32": [_p, _p, _i64, _i, _i64, _p],
 }
+if AB_VARIANT:
+    SIGNATURES["tg_step_sparse_i8"] = [_p, _p, _p, _p, _p, _i64, _i, _i64, _i, _p]
 
 
 def _preload_torch_hip_runtime() -> None:
@@ -67,7 +73,7 @@ def _load() -> C.CDLL:
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP library is not built.  Run "
-            "`python -c 'import __graft_entry__ as g; g.build()'` (or `python -m mat_mul_amd.build`). "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `python -m mat_mul_amd.build [--ab]`). "
             "mat_mul_amd has no CPU fallback."
         )
     lib = C.CDLL(str(LIB_PATH))

@@ -1,17 +1,35 @@
-"""Build libtensorgame.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+"""Build libtensorgame.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+Every HIP source is compiled to its own object (in parallel, re-compiled only when it or a header
+is newer) and the objects are linked into ``mat_mul_amd/lib/libtensorgame.so``.
+
+Two variants:
+  * the PRODUCT library (default): no environment switches, no measurement-only kernels;
+  * the A/B library ``libtensorgame_ab.so`` (``build(ab=True)``, compiled with -DTG_AB_SWITCHES): the
+    same sources plus the getenv A/B switches, the first-generation 32-bit cursor kernels and the
+    nnz-carrying sparse step (tg_step_sparse_i8).  Loaded only when TG_LIB_VARIANT=ab is set
+    (tests/test_gpu_parity.py::test_ab_switch_paths_stay_exact, tools/).
+"""
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+import time
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
+OBJ_DIR = LIB_DIR / "obj"
 LIB_PATH = LIB_DIR / "libtensorgame.so"
-SOURCES = [CSRC / "tg_kernels.hip", CSRC / "tg_gen.hip", CSRC / "tg_aux.hip"]
-HEADERS = [CSRC / "tg_device.h", CSRC / "tg_packed.h", CSRC / "tg_rows.h", CSRC / "tg_mfma.h", PKG.parent / "include" / "tensor_game.h"]
+LIB_PATH_AB = LIB_DIR / "libtensorgame_ab.so"
+SOURCES = sorted(CSRC.glob("*.hip"))
+HEADERS = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "tensor_game.h"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
+         "-mllvm", "-amdgpu-mfma-vgpr-form",  # MFMA results in VGPRs (tg_mfma.h): no v_accvgpr moves
+         "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:
@@ -21,28 +39,63 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
-def is_stale() -> bool:
-    if not LIB_PATH.exists():
-        return True
-    t = LIB_PATH.stat().st_mtime
-    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
+def lib_path(ab: bool = False) -> Path:
+    return LIB_PATH_AB if ab else LIB_PATH
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP source into mat_mul_amd/lib/libtensorgame.so (gfx950 only)."""
-    if not force and not is_stale():
-        return LIB_PATH
-    LIB_DIR.mkdir(parents=True, exist_ok=True)
-    cmd = [_hipcc(), "-O3", "-std=c++17", "-shared", "-fPIC", "--offload-arch=gfx950",
-           "-mllvm", "-amdgpu-mfma-vgpr-form",  # MFMA results in VGPRs (tg_mfma.h): no v_accvgpr moves
-           "-Wall", "-Wno-unused-function", *map(str, SOURCES), "-o", str(LIB_PATH)]
+def _newest_input() -> float:
+    return max(p.stat().st_mtime for p in SOURCES + HEADERS + [Path(__file__)])
+
+
+def is_stale(ab: bool = False) -> bool:
+    lib = lib_path(ab)
+    return (not lib.exists()) or lib.stat().st_mtime < _newest_input()
+
+
+def _obj(src: Path, ab: bool) -> Path:
+    return OBJ_DIR / f"{src.stem}{'.ab' if ab else ''}.o"
+
+
+def build(force: bool = False, verbose: bool = False, ab: bool = False) -> Path:
+    """Compile every HIP source (gfx950 only) and link the chosen variant of the library."""
+    lib = lib_path(ab)
+    if not force and not is_stale(ab):
+        return lib
+    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+    hipcc = _hipcc()
+    hdr_time = max(p.stat().st_mtime for p in HEADERS + [Path(__file__)])
+    extra = ["-DTG_AB_SWITCHES"] if ab else []
+
+    def compile_one(src: Path):
+        obj = _obj(src, ab)
+        if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_time):
+            return src, 0.0, None
+        cmd = [hipcc, *FLAGS, *extra, "-c", str(src), "-o", str(obj)]
+        t0 = time.perf_counter()
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            return src, time.perf_counter() - t0, f"{' '.join(cmd)}\n{res.stdout}\n{res.stderr}"
+        if verbose and res.stderr.strip():
+            print(res.stderr.strip())
+        return src, time.perf_counter() - t0, None
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    for src, dt, err in results:
+        if err:
+            raise RuntimeError(f"hipcc failed on {src.name}:\n{err}")
+        if verbose:
+            print(f"  {src.name}: {'up to date' if dt == 0.0 else f'{dt:.1f} s'}")
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *[str(_obj(s, ab)) for s in SOURCES], "-o", str(lib)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
-    return LIB_PATH
+        raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    print(build(force="--force" in sys.argv, verbose=True, ab="--ab" in sys.argv))

@@ -3,6 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Measurement switches (environment variables) exist only in the A/B build (mat_mul_amd/build.py, ab=True);
+// in the product library TG_SWITCH() is the constant false and no entry point reads the environment.
+#ifdef TG_AB_SWITCHES
+#include <cstdlib>
+#define TG_SWITCH(name) ([]() -> bool { static const bool v = getenv(name) != nullptr; return v; }())
+#else
+#define TG_SWITCH(name) false
+#endif
+
 namespace tg {
 
 constexpr int kBlock = 256;  // 4 wavefronts of 64

@@ -559,7 +559,7 @@ int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, 
   if (basis) {
     const size_t lds = 3 * static_cast<size_t>(S) * S * sizeof(int) + 64 * 3 * static_cast<size_t>(S);
     const dim3 bgrid(grid_for(B > 16384 ? 16384 : B)), bblock(192);
-    static const bool no_mfma = getenv("TG_NO_MFMA") != nullptr;  // A/B switch for measurements
+    const bool no_mfma = TG_SWITCH("TG_NO_MFMA");  // A/B switch for measurements
     const int mjob = 3 * ((R + 31) / 32);
     const dim3 mgrid(grid_for(B > 65536 ? 65536 : B)), mblock(64 * (mjob < 8 ? mjob : 8));
     switch (no_mfma ? -S : S) {
@@ -584,9 +584,16 @@ int tg_sample_basis_i8(int8_t* basis_out, int8_t* lower_out, int8_t* upper_out, 
   if (B < 0 || S < 1 || S > TG_MAX_S) return tg_internal_fail(TG_ERR_INVALID, "%s: bad B/S", fn);
   tg::Dist D;
   if (int rc = make_dist(fn, thresholds, values, n_values, &D)) return rc;
+  // P = L U is narrowed to int8: an entry is a sum of at most S products of two cells, so every value v of
+  // the distribution must satisfy S * v^2 <= 127 (with the +-1 diagonals the bound is never exceeded then);
+  // beyond that the product could wrap silently and P would not be L U
+  for (int t = 0; t < n_values; ++t)
+    if (S * static_cast<int>(values[t]) * static_cast<int>(values[t]) > 127)
+      return tg_internal_fail(TG_ERR_INVALID, "%s: value %d too large for S=%d (need S*v^2 <= 127: P = L*U must fit int8)",
+                              fn, (int)values[t], S);
   if (B == 0) return TG_OK;
   if (!basis_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
-  static const bool no_mfma = getenv("TG_NO_MFMA") != nullptr;  // A/B switch for measurements
+  const bool no_mfma = TG_SWITCH("TG_NO_MFMA");  // A/B switch for measurements
   (void)hipGetLastError();
   if (!no_mfma)  // one wavefront per matrix, four per workgroup
     hipLaunchKernelGGL(tg::sample_basis_mfma_kernel, dim3(grid_for((3 * B + 3) / 4)), dim3(tg::kBlock), 0,

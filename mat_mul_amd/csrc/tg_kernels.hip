@@ -1,17 +1,25 @@
 // libtensorgame.so -- hand-written gfx950 (MI355X, CDNA4) kernels for the tensor-game hot path
-// and the C ABI of include/tensor_game.h.  No MFMA anywhere: the path is HBM-bound byte work
-// (state <- state - u(x)v(x)w, zero check, rank-1 accumulation), see DESIGN.md.
+// and the C ABI of include/tensor_game.h.  The single step, expand and the other byte-streaming
+// entries are HBM-bound byte work on the vector ALU (state <- state - u(x)v(x)w, zero check); the
+// accumulations over many rank-1 terms (generator, long step_many lists) run on the int8 matrix
+// cores (tg_mfma.h).  See DESIGN.md.
 //
 // Kernel families
 //   slow_*   : one 256-thread workgroup per game, byte-granular.  Any S <= TG_MAX_S, any alignment.
-//   team_*   : aligned layouts (base, stride multiples of 16 B).  A "team" of TS consecutive lanes
-//              owns one game; each lane streams 16-byte chunks (global_load/store_dwordx4), the
-//              factor tokens of the team's games are staged in LDS, the zero check is a wavefront
-//              ballot (TS <= 64) or a workgroup OR (TS = 256).  Instantiated for S = 4, 9, 16, 25.
 //   s4_*     : S = 4 in registers only: 4 lanes per game (16 games per wavefront), one dwordx4
 //              per lane, tokens as three dwords per lane, ballot nibble for the zero check.
+//   s16_step : S = 16 single step, one wavefront per game, registers only.
+//   packed_* / rows_* (tg_packed.h, tg_rows.h): aligned layouts, 16-byte chunks, int16 pairs.
+//   *_mfma_* (tg_mfma.h): accumulation over many terms on the matrix cores.
+//   team_*   : the first-generation 32-bit cursor kernels; compiled only into the A/B library
+//              (-DTG_AB_SWITCHES, mat_mul_amd/build.py) as a measurement reference.
+//
+// The PRODUCT build reads no environment variable and keeps no mutable host state besides per-device
+// caches of device constants (atomics): TG_SWITCH() is constant false.  The A/B build (-DTG_AB_SWITCHES)
+// turns the TG_* environment switches on and adds team_kernel and tg_step_sparse_i8.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -238,6 +246,7 @@ __device__ __forceinline__ void store_chunk(int8_t* p, const uint4& q, bool tail
   *reinterpret_cast<uint4*>(p) = q;
 }
 
+#ifdef TG_AB_SWITCHES
 // The exact 32-bit form: any factor magnitude.  Body of team_kernel, and the fallback of the
 // packed-int16 kernels (tg_packed.h) for games whose factors are too large for 16-bit sums.
 template <int S, int TS, int MODE>
@@ -415,6 +424,8 @@ __global__ __launch_bounds__(kBlock) void team_kernel(ApplyArgs a) {
   __shared__ uint8_t nzf[(MODE == MANY && TS == 256) ? TG_MAX_ACTIONS : 4];
   team_body_i32<S, TS, MODE>(a, lds, nzf);
 }
+
+#endif  // TG_AB_SWITCHES
 
 #include "tg_packed.h"
 #include "tg_rows.h"
@@ -898,6 +909,37 @@ __global__ __launch_bounds__(kBlock) void matmul_template_kernel(int8_t* dst, in
   }
 }
 
+// dst[b] <- src[b] for b < B: one thread per 16-byte chunk of a game (the mapping of the step kernels without
+// their arithmetic), grid = all chunks.  SH >= 0: chunks per game = 1 << SH (S = 4, 8, 16: shifts instead of a
+// division).  The padding between games is neither read nor written.  vec16 == 0: byte granularity.
+__global__ __launch_bounds__(kBlock) void copy_kernel(const int8_t* src, int8_t* dst, int64_t B, int nchunk, int sh,
+                                                      int tailb, int64_t sstride, int64_t dstride) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  int64_t g;
+  int c;
+  if (sh >= 0) {
+    g = idx >> sh;
+    c = static_cast<int>(idx) & (nchunk - 1);
+  } else {
+    g = idx / nchunk;
+    c = static_cast<int>(idx - g * nchunk);
+  }
+  if (g >= B) return;
+  const int8_t* s = src + g * sstride + 16 * c;
+  int8_t* d = dst + g * dstride + 16 * c;
+  if (tailb != 0 && c == nchunk - 1) {  // the game's last chunk holds only tailb bytes
+    for (int t = 0; t < tailb; ++t) d[t] = s[t];
+  } else {
+    *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void copy_bytes_kernel(const int8_t* src, int8_t* dst, int64_t B, int N,
+                                                            int64_t sstride, int64_t dstride) {
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x)
+    for (int e = threadIdx.x; e < N; e += kBlock) dst[b * dstride + e] = src[b * sstride + e];
+}
+
 }  // namespace tg
 
 // =============================================================================================
@@ -934,16 +976,47 @@ int validate_common(const char* fn, int64_t B, int S, int64_t stride) {
   return TG_OK;
 }
 
-int device_cu_count() {  // of the current device; 256 on MI355X
-  static int cached[64] = {0};
+// Per-device caches of device constants.  Entries are written with relaxed atomics: two host threads racing
+// on a cold entry both query and store the same value.  Nothing else in the library is mutable host state.
+constexpr int kMaxDevices = 64;
+
+int current_device() {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (!cached[dev]) {
-    int n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
+  return dev;
+}
+
+int device_cu_count() {  // of the current device; 256 on MI355X
+  static std::atomic<int> cached[kMaxDevices];
+  const int dev = current_device();
+  if (dev < 0) return 256;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (!n) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-    cached[dev] = n;
+    cached[dev].store(n, std::memory_order_relaxed);
   }
-  return cached[dev];
+  return n;
+}
+
+// Workgroups of `kernel` one CU holds at `lds` bytes of dynamic LDS, cached per (kernel instantiation, device):
+// the slot packs (lds + 1) << 32 | value, so a different LDS size simply re-queries.  The query is a host-side
+// calculation on the code object (no stream operation), so it is legal while `st` is being captured.
+struct OccupancySlots {
+  std::atomic<uint64_t> v[kMaxDevices];
+};
+template <typename K>
+int resident_per_cu(K kernel, int lds, OccupancySlots& slots) {
+  const int dev = current_device();
+  const uint64_t tag = (static_cast<uint64_t>(lds) + 1) << 32;
+  if (dev >= 0) {
+    const uint64_t c = slots.v[dev].load(std::memory_order_relaxed);
+    if ((c & ~0xffffffffull) == tag) return static_cast<int>(c & 0xffffffffull);
+  }
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, tg::kBlock, lds) != hipSuccess || n < 1) n = 1;
+  (void)hipGetLastError();
+  if (dev >= 0) slots.v[dev].store(tag | static_cast<uint32_t>(n), std::memory_order_relaxed);
+  return n;
 }
 
 unsigned capped_grid(int64_t blocks) {
@@ -959,6 +1032,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
   const bool al = (MODE == GENF || (aligned16(a.in) && a.in_stride % 16 == 0)) && aligned16(a.out) &&
                   a.out_stride % 16 == 0;
   const int64_t B = a.B;
+#ifdef TG_AB_SWITCHES
 #define TG_TEAM(S_, TS_)                                                                        \
   do {                                                                                          \
     const int64_t blocks = (B + Geo<S_, TS_>::GPB - 1) / Geo<S_, TS_>::GPB;                     \
@@ -966,11 +1040,12 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     (void)hipGetLastError(); hipLaunchKernelGGL((team_kernel<S_, TS_, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a); \
     return check_launch(fn);                                                                    \
   } while (0)
+#endif
   if (al && a.S == 4 && aligned4(a.actions) && a.in_stride < (1 << 20) && a.out_stride < (1 << 20)) {
     const int64_t blocks = (B * 4 + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
     if constexpr (MODE == EXPAND) {
-      static const bool per_parent = getenv("TG_S4_EXPAND_PER_PARENT") != nullptr;  // A/B switch for measurements
+      const bool per_parent = TG_SWITCH("TG_S4_EXPAND_PER_PARENT");  // A/B switch for measurements
       if (a.nact <= 64 && a.out_stride * 64 < (1 << 24) && !per_parent) {
         const int PB = 64 / a.nact, recip = (65536 + a.nact - 1) / a.nact;
         const int64_t eblocks = (B + PB - 1) / PB;
@@ -990,7 +1065,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     const int64_t n = (MODE == GENF) ? a.nact : 1;  // STEP, STEPS, EXPAND: one action per result
     while (flim < 31 && static_cast<int64_t>(flim + 1) * (flim + 1) * (flim + 1) * n <= 32000) ++flim;
   }
-  static const bool force_i32 = getenv("TG_FORCE_I32") != nullptr;  // A/B switch for measurements
+  const bool force_i32 = TG_SWITCH("TG_FORCE_I32");  // A/B switch for measurements
 #define TG_PACKED(S_, TS_)                                                                      \
   do {                                                                                          \
     const int64_t blocks = (B + PGeo<S_, TS_>::GPB - 1) / PGeo<S_, TS_>::GPB;                   \
@@ -1013,7 +1088,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
                        ldsb, st, a, flim, at);                                                  \
     return check_launch(fn);                                                                    \
   } while (0)
-  static const bool no_mfma = getenv("TG_NO_MFMA") != nullptr;  // A/B switch for measurements
+  const bool no_mfma = TG_SWITCH("TG_NO_MFMA");  // A/B switch for measurements
   if constexpr (MODE == GENF) {
     // the accumulation over R is a dense contraction: matrix cores (tg_mfma.h); u*v must fit int8 (checked
     // on device, per game), the transposed factors of one game must fit LDS
@@ -1022,14 +1097,8 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
   do {                                                                                           \
     /* a workgroup's set-up (tile offsets, staging addresses) is a third of one game's work: give every */ \
     /* workgroup several games, as many workgroups as the chip holds at once, games split evenly */ \
-    static int occ_lds = -1, occ_val = 1;  /* per instantiation; a stale value only changes the grid shape */ \
-    if (occ_lds != ldsb) {                                                                       \
-      int v = 0;                                                                                 \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, genf_mfma_kernel<S_, KS_>, kBlock, ldsb) != hipSuccess || v < 1) v = 1; \
-      occ_val = v;                                                                               \
-      occ_lds = ldsb;                                                                            \
-    }                                                                                            \
-    const int per_cu = occ_val;                                                                  \
+    static OccupancySlots occ;                                                                   \
+    const int per_cu = resident_per_cu(genf_mfma_kernel<S_, KS_>, ldsb, occ);                    \
     const int64_t resident = static_cast<int64_t>(per_cu) * device_cu_count();                   \
     const int64_t per_wg = (B + resident - 1) / resident;                                        \
     const int64_t grid = (B + per_wg - 1) / per_wg;                                              \
@@ -1041,7 +1110,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
   do {                                                                                           \
     const int Rp = (a.nact + 31) & ~31;                                                          \
     const int ldsb = mfma_lds_bytes<S_>(Rp);                                                     \
-    static const bool ks0 = getenv("TG_MFMA_KS0") != nullptr;                                    \
+    const bool ks0 = TG_SWITCH("TG_MFMA_KS0");                                                   \
     if (Rp == 32 && !ks0) TG_MFMA_K(S_, 1);                                                      \
     if (Rp == 64 && !ks0) TG_MFMA_K(S_, 2);                                                      \
     TG_MFMA_K(S_, 0);                                                                            \
@@ -1060,21 +1129,15 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     // Where it pays (measured, tools/sweep_many.py): the per-game set-up (transposed factors, input image,
     // per-action scalars, verdict) outweighs the lattice kernels' K S^3 MACs only for long action lists; beyond
     // K = 127 the overflow bound cannot certify the reference's {-1,0,1} factors any more.
-    static const bool many_always = getenv("TG_MFMA_MANY_ALWAYS") != nullptr;  // tests: every eligible shape
+    const bool many_always = TG_SWITCH("TG_MFMA_MANY_ALWAYS");  // tests: every eligible shape
     const bool pays = a.nact <= 127 && ((a.S == 25 && a.nact >= 12) || (a.S == 16 && a.nact >= 40) || (a.S == 9 && a.nact >= 48));
     if (al && a.nact <= 256 && !force_i32 && !no_mfma && (a.S == 9 || a.S == 16 || a.S == 25) && (pays || many_always)) {
       const int Rp = (a.nact + 31) & ~31;
 #define TG_MANY_K(S_, KS_)                                                                       \
   do {                                                                                           \
     const int ldsb = many_mfma_lds_bytes<S_>(Rp);                                                \
-    static int occ_lds = -1, occ_val = 1;                                                        \
-    if (occ_lds != ldsb) {                                                                       \
-      int v = 0;                                                                                 \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, many_mfma_kernel<S_, KS_>, kBlock, ldsb) != hipSuccess || v < 1) v = 1; \
-      occ_val = v;                                                                               \
-      occ_lds = ldsb;                                                                            \
-    }                                                                                            \
-    const int64_t resident = static_cast<int64_t>(occ_val) * device_cu_count();                  \
+    static OccupancySlots occ;                                                                   \
+    const int64_t resident = static_cast<int64_t>(resident_per_cu(many_mfma_kernel<S_, KS_>, ldsb, occ)) * device_cu_count(); \
     const int64_t per_wg = (B + resident - 1) / resident;                                        \
     const int64_t grid = (B + per_wg - 1) / per_wg;                                              \
     (void)hipGetLastError();                                                                     \
@@ -1095,7 +1158,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
       a.only_flagged = 1;
     }
   }
-  static const bool no_rows = getenv("TG_NO_ROWS") != nullptr;  // A/B switch for measurements
+  const bool no_rows = TG_SWITCH("TG_NO_ROWS");  // A/B switch for measurements
   if constexpr (MODE == MANY || MODE == GENF) {
     // odd S, several actions: each lane owns whole rows (tg_rows.h); the LDS transposition is
     // amortised over the actions
@@ -1105,7 +1168,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     }
   }
 #undef TG_ROWS
-  static const bool no_s16 = getenv("TG_NO_S16_DIRECT") != nullptr;  // A/B switch for measurements
+  const bool no_s16 = TG_SWITCH("TG_NO_S16_DIRECT");  // A/B switch for measurements
   if constexpr (MODE == STEP) {
     if (al && a.S == 16 && aligned16(a.actions) && !force_i32 && !no_s16) {
       const int64_t blocks = (B + 3) / 4;
@@ -1123,12 +1186,14 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     if (a.S == 25) TG_PACKED(25, 256);
   }
 #undef TG_PACKED
+#ifdef TG_AB_SWITCHES
   if constexpr (MODE != STEPS) {  // the 32-bit cursor kernels (A/B reference) have no nnz-carrying step
     if (al && a.S == 9) TG_TEAM(9, 64);
     if (al && a.S == 16) TG_TEAM(16, 64);
     if (al && a.S == 25) TG_TEAM(25, 256);
   }
 #undef TG_TEAM
+#endif
   (void)hipGetLastError(); hipLaunchKernelGGL((slow_kernel<MODE>), dim3(capped_grid(B)), dim3(kBlock), 0, st, a);
   return check_launch(fn);
 }
@@ -1160,6 +1225,7 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
   return launch_apply<tg::STEP>("tg_step_i8", a, static_cast<hipStream_t>(stream));
 }
 
+#ifdef TG_AB_SWITCHES
 int tg_step_sparse_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_t* done, uint8_t* overflow,
                       int64_t B, int S, int64_t game_stride_bytes, int shift, tg_stream_t stream) {
   if (int rc = validate_common("tg_step_sparse_i8", B, S, game_stride_bytes)) return rc;
@@ -1169,6 +1235,7 @@ int tg_step_sparse_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_
                   game_stride_bytes, game_stride_bytes, S, 1, shift};
   return launch_apply<tg::STEPS>("tg_step_sparse_i8", a, static_cast<hipStream_t>(stream));
 }
+#endif  // TG_AB_SWITCHES
 
 int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
                     int32_t* done_step, uint8_t* overflow, int64_t B, int S, int K,
@@ -1207,6 +1274,32 @@ int tg_gen_from_factors_i8(const int8_t* actions, int8_t* target_out, uint8_t* o
   tg::ApplyArgs a{nullptr, target_out, actions, nullptr, nullptr, nullptr, overflow, B,
                   game_stride_bytes, game_stride_bytes, S, R, shift};
   return launch_apply<tg::GENF>("tg_gen_from_factors_i8", a, static_cast<hipStream_t>(stream));
+}
+
+int tg_copy_i8(const int8_t* state_in, int8_t* state_out, int64_t B, int S, int64_t in_stride_bytes,
+               int64_t out_stride_bytes, tg_stream_t stream) {
+  if (int rc = validate_common("tg_copy_i8", B, S, in_stride_bytes)) return rc;
+  if (int rc = validate_common("tg_copy_i8", B, S, out_stride_bytes)) return rc;
+  if (B == 0) return TG_OK;
+  if (!state_in || !state_out) return fail(TG_ERR_INVALID, "tg_copy_i8: null pointer");
+  if (state_in == state_out) return in_stride_bytes == out_stride_bytes ? TG_OK : fail(TG_ERR_INVALID, "tg_copy_i8: in place with different strides");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int N = S * S * S;
+  (void)hipGetLastError();
+  if (aligned16(state_in) && aligned16(state_out) && in_stride_bytes % 16 == 0 && out_stride_bytes % 16 == 0) {
+    const int nchunk = (N + 15) / 16;
+    int sh = -1;
+    for (int t = 0; t < 12; ++t)
+      if ((1 << t) == nchunk) sh = t;
+    const int64_t blocks = (B * nchunk + tg::kBlock - 1) / tg::kBlock;
+    if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "tg_copy_i8: B too large");
+    hipLaunchKernelGGL(tg::copy_kernel, dim3((unsigned)blocks), dim3(tg::kBlock), 0, st, state_in, state_out, B, nchunk,
+                       sh, N % 16, in_stride_bytes, out_stride_bytes);
+  } else {
+    hipLaunchKernelGGL(tg::copy_bytes_kernel, dim3(capped_grid(B > 65536 ? 65536 : B)), dim3(tg::kBlock), 0, st, state_in,
+                       state_out, B, N, in_stride_bytes, out_stride_bytes);
+  }
+  return check_launch("tg_copy_i8");
 }
 
 int tg_done_i8(const int8_t* state, uint8_t* done, int32_t* nnz, int64_t B, int S,

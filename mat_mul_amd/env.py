@@ -41,6 +41,11 @@ class TensorGameEnv:
         # incremental=True (dim_t == 1 only): the env carries every game's non-zero count, and a step then
         # touches only the chunks its action changes (tg_step_sparse_i8) instead of the whole state
         self.incremental = bool(incremental) and self.T == 1
+        if self.incremental:
+            from . import _lib
+            if not _lib.AB_VARIANT:
+                raise TensorGameError("TensorGameEnv", -2, "incremental=True needs tg_step_sparse_i8, which exists only in "
+                                      "the A/B library (TG_LIB_VARIANT=ab); it is slower than the default step")
         self._nnz = torch.zeros((self.B,), dtype=torch.int32, device=self.device) if self.incremental else None
         self._nnz_valid = False
         self.done = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
@@ -160,6 +165,11 @@ class TensorGameEnv:
         if actions.dtype != torch.int8:
             actions = ops.as_tokens(actions, self.device)
         return ops.expand(self.state, actions, shift=self.shift)
+
+    def snapshot(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """A copy of the current head states (the reference's step is functional: callers such as the tree search
+        keep the parent, act.py:183-195; here the step is in place, so keeping a parent is an explicit copy)."""
+        return ops.copy_states(self.state, out)
 
     def model_input(self, dtype=torch.float32):
         """(state (B,T,S,S,S) float, scalars (B,1)) as AlphaTensor.fwd_* consume them

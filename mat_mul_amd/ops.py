@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import TG_MAX_ACTIONS, TG_MAX_S, TG_MAX_VALUES, TensorGameError, call
 
 __all__ = [
-    "step", "step_sparse", "prepare_step", "step_many", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
+    "step", "step_sparse", "copy_states", "prepare_step", "step_many", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
     "gen_demos", "sample_basis", "change_basis", "as_tokens", "categorical_thresholds",
     "alloc_states", "alloc_ring", "emit_frames", "state_hash", "slice_rank",
 ]
@@ -122,6 +122,9 @@ def step_sparse(state, actions, nnz, done=None, overflow=None, shift: int = 1):
     exact on entry, updated in place) lets the kernel skip loading and storing every chunk the action
     does not touch.  Same results as ``step(state, actions, out=state)``; done[b] = (nnz[b] == 0).
     Returns (state, done)."""
+    if not _lib.AB_VARIANT:
+        raise TensorGameError("step_sparse", -2, "tg_step_sparse_i8 exists only in the A/B library "
+                              "(set TG_LIB_VARIANT=ab before importing mat_mul_amd); it is slower than step()")
     B, S, stride = _state_layout(state, "state")
     dev = state.device
     actions = _tokens(actions, (B,), S, dev, "actions")
@@ -136,6 +139,21 @@ def step_sparse(state, actions, nnz, done=None, overflow=None, shift: int = 1):
         call("tg_step_sparse_i8", _ptr(state), _ptr(actions), _ptr(nnz), _ptr(done), _ptr(overflow),
              B, S, stride, int(shift), _stream(dev))
     return state, done
+
+
+def copy_states(state, out=None):
+    """out[b] = state[b] (a snapshot of a batch of games; the reference's step is functional and its callers
+    keep the parent, act.py:183-195).  ``out`` may have a different game stride.  Returns out."""
+    B, S, stride = _state_layout(state, "state")
+    dev = state.device
+    if out is None:
+        out = alloc_states(B, S, dev, zero=False)
+    Bo, So, ostride = _state_layout(out, "out")
+    if (Bo, So) != (B, S) or out.device != dev:
+        raise TensorGameError("copy_states", -1, "out must match state's shape and device")
+    with torch.cuda.device(dev):
+        call("tg_copy_i8", _ptr(state), _ptr(out), B, S, stride, ostride, _stream(dev))
+    return out
 
 
 def prepare_step(state, actions_seq, done, overflow=None, shift: int = 1):
@@ -201,7 +219,15 @@ def expand(state, actions, out=None, done=None, changed=None, overflow=None, shi
         out = alloc_states(B * k, S, dev, zero=False).unflatten(0, (B, k))
     if out.dtype != torch.int8 or tuple(out.shape) != (B, k, S, S, S) or out.device != dev:
         raise TensorGameError("expand", -1, f"out must be int8 {(B, k, S, S, S)} on {dev}")
-    _, _, ostride = _state_layout(out.flatten(0, 1), "out")
+    # child (b, i) lives at base + (b*k + i) * ostride: the (B, k) dims must collapse to ONE stride.  No
+    # flatten() here -- on a view that cannot be flattened it would silently copy and the kernel would write
+    # through the original pointer with the copy's strides
+    if out.stride()[2:] != (S * S, S, 1):
+        raise TensorGameError("expand", -1, "out: each child must be C-contiguous (S,S,S)")
+    ostride = out.stride(1) if k > 1 else (out.stride(0) if B > 1 else max(out.stride(1), S ** 3))
+    if ostride < S ** 3 or (B > 1 and k > 1 and out.stride(0) != k * ostride):
+        raise TensorGameError("expand", -1, f"out: children must be evenly spaced (strides {out.stride()[:2]}); "
+                                            "a slice like big[:, :k] of a wider buffer is not")
     if done is None:
         done = torch.empty((B, k), dtype=torch.uint8, device=dev)
     if changed is None:
@@ -332,6 +358,8 @@ def sample_basis(B: int, S: int, device, values=(-1, 0, 1), probs=None, seed: in
         p = min(0.15, 0.4 / S)
         probs = (p, 1.0 - 2.0 * p, p)
     thr, vals, thr_p, val_p, nv = _dist(values, probs, "sample_basis")
+    if (S * vals.astype(np.int64) ** 2 > 127).any():  # the library enforces the same rule
+        raise TensorGameError("sample_basis", -1, f"every value needs S*v^2 <= 127 at S={S}: P = L @ U is emitted as int8")
     P = torch.empty((B, 3, S, S), dtype=torch.int8, device=dev)
     L = torch.empty_like(P) if want_factors else None
     U = torch.empty_like(P) if want_factors else None

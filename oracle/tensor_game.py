@@ -323,8 +323,11 @@ def sample_basis(B, S, thresholds, values, seed, game_id_offset=0):
     One 32-bit draw per cell (a,b) of each matrix: a>b -> L[a,b]; a<b -> U[a,b];
     a==b -> bit0 = sign of L[a,a], bit1 = sign of U[a,a].
     Counter = (gid_lo, gid_hi, STREAM_BASIS | mode, block) with block = (a*S+b)//4.
+    Values must satisfy S * v^2 <= 127 (P is emitted as int8; the library refuses larger ones).
     Returns (P int64 (B,3,S,S), L, U)."""
     values = np.asarray(values, np.int64)
+    if (S * values * values > 127).any():
+        raise ValueError("sample_basis: need S * v^2 <= 127 for every value (P = L @ U must fit int8)")
     thr = np.asarray(thresholds, np.uint32)
     gid = np.arange(B, dtype=np.uint64) + np.uint64(game_id_offset)
     nblk = (S * S + 3) // 4

@@ -1,31 +1,41 @@
 #!/bin/bash
 # Profiling recipe for one round (run on the GPU box via gpurun from the repo root):
-#   bash profiles/run_profiles.sh r01
-# Writes raw rocprofv3 output under gpurun_out/prof_<tag>/ ; copy the *_stats.csv summaries into profiles/.
+#   bash profiles/run_profiles.sh r02
+# Writes raw rocprofv3 output under gpurun_out/prof_<tag>/ ; `python profiles/summarize.py <tag>` then condenses
+# it into the small files committed under profiles/.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# 1. kernel trace + stats of the default bench command (hipGraph replay), no CPU leg, headline workload only
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_graph -o bench_graph -- python3 $R/bench.py --no-cpu-baseline --no-also > $OUT/bench_graph.json 2> $OUT/bench_graph.err || exit 1
+LEAN="--no-cpu-baseline --no-also"
+# 0. unprofiled: the driver's own command (what BENCH_rNN.json records) and the default command, full JSON lines
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err || exit 1
+python3 $R/bench.py $LEAN > $OUT/bench_default_lean.json 2> $OUT/bench_default_lean.err || exit 1
+# 1. kernel trace + stats of the driver's command and of the default command (hipGraph replay), headline workload only
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_driver -o bench_driver -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 $LEAN > $OUT/bench_driver.json 2> $OUT/bench_driver.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_graph -o bench_graph -- python3 $R/bench.py $LEAN > $OUT/bench_graph.json 2> $OUT/bench_graph.err || exit 1
 # 1b. the same for BASELINE config 3 (S=16, B=8192)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_graph_S16 -o bench_graph_S16 -- python3 $R/bench.py --dim 16 --steps 512 --warmup 64 --no-cpu-baseline --no-also > $OUT/bench_graph_S16.json 2> $OUT/bench_graph_S16.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_graph_S16 -o bench_graph_S16 -- python3 $R/bench.py --dim 16 --steps 512 --warmup 64 $LEAN > $OUT/bench_graph_S16.json 2> $OUT/bench_graph_S16.err || exit 1
 # 2. the same in eager mode (one ctypes launch per step)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_eager -o bench_eager -- python3 $R/bench.py --mode eager --no-cpu-baseline --no-also > $OUT/bench_eager.json 2> $OUT/bench_eager.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_eager -o bench_eager -- python3 $R/bench.py --mode eager --steps 504 --warmup 56 --samples 3 $LEAN > $OUT/bench_eager.json 2> $OUT/bench_eager.err || exit 1
 # 3. HBM traffic counters, one pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass), eager, few steps
-for wl in "4 65536" "4 4194304" "16 8192" "16 131072" "25 4096"; do
+for wl in "4 65536" "4 1048576" "4 4194304" "16 8192" "16 131072" "25 4096"; do
   set -- $wl
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_S$1_B$2_$ctr -o pmc -- python3 $R/bench.py --mode eager --steps 56 --warmup 14 --dim $1 --batch $2 --no-cpu-baseline --no-also > $OUT/pmc_S$1_B$2_$ctr.json 2> $OUT/pmc_S$1_B$2_$ctr.err || exit 1
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_S$1_B$2_$ctr -o pmc -- python3 $R/bench.py --mode eager --steps 28 --warmup 14 --samples 2 --dim $1 --batch $2 $LEAN > $OUT/pmc_S$1_B$2_$ctr.json 2> $OUT/pmc_S$1_B$2_$ctr.err || exit 1
   done
 done
-# 4. the generator of BASELINE config 5 (tokens -> change of basis -> accumulation on the matrix cores)
+# 4. the generator of BASELINE config 5, plain and in a random basis
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/generator -o generator -- python3 $R/tools/prof_basis.py > $OUT/generator.log 2> $OUT/generator.err || exit 1
 # 5. the matrix-core kernels under PMC counters (what bounds them: DESIGN.md section 3)
-for op in genf many; do
+for op in gen genf many; do
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/mfma_${op}_p1 -o pmc -- python3 $R/tools/prof_one.py --op $op --S 25 --B 4096 --R 64 --iters 5 > $OUT/mfma_${op}_p1.log 2>&1 || exit 1
   rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/mfma_${op}_p2 -o pmc -- python3 $R/tools/prof_one.py --op $op --S 25 --B 4096 --R 64 --iters 5 > $OUT/mfma_${op}_p2.log 2>&1 || exit 1
 done
+# 6. the launch floor at BASELINE config 2: empty kernel / copy / step variants as hipGraphs of 2000 chained launches
+hipcc -O3 -std=c++17 --offload-arch=gfx950 $R/tools/microbench_step.hip -L$R/mat_mul_amd/lib -ltensorgame -o $OUT/microbench_step > $OUT/microbench_build.log 2>&1 || exit 1
+LD_LIBRARY_PATH=$R/mat_mul_amd/lib:$LD_LIBRARY_PATH $OUT/microbench_step 65536 2000 > $OUT/launch_floor.txt 2> $OUT/launch_floor.err || exit 1
+rm -f $OUT/microbench_step
 echo profiles done

@@ -22,6 +22,8 @@ def pytest_sessionstart(session):
 
     if build.is_stale():
         build.build(verbose=True)
+    if build.is_stale(ab=True):  # the A/B variant (tests/test_gpu_ab_library.py) travels to the GPU box too
+        build.build(verbose=True, ab=True)
 
 
 @pytest.fixture(scope="session")

@@ -13,8 +13,10 @@ from mat_mul_amd import _lib, ops, shard_range
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def declared_symbols():
+def declared_symbols(ab=False):
     text = (ROOT / "include" / "tensor_game.h").read_text()
+    if not ab:  # drop what the header declares for the A/B build only
+        text = re.sub(r"#ifdef TG_AB_SWITCHES.*?#endif", "", text, flags=re.S)
     return sorted(set(re.findall(r"^(?:int|const char\*)\s+(tg_[a-z0-9_]+)\s*\(", text, flags=re.M)))
 
 
@@ -26,6 +28,14 @@ def test_header_symbols_all_exported():
     for s in syms:
         assert hasattr(lib, s), s
     assert lib.tg_abi_version() == 1
+    # the A/B variant exports the same entries plus the measurement-only one
+    from mat_mul_amd import build
+    extra = sorted(set(declared_symbols(ab=True)) - set(syms))
+    assert extra == ["tg_step_sparse_i8"]
+    ab = C.CDLL(str(build.lib_path(ab=True)))
+    for s in syms + extra:
+        assert hasattr(ab, s), s
+    assert not hasattr(lib, "tg_step_sparse_i8")
 
 
 def test_argument_validation_without_gpu():

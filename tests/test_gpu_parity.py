@@ -487,9 +487,10 @@ def test_basis(S):
 
 
 # ------------------------------------------------------------------ full-size properties (BASELINE configs)
-@pytest.mark.parametrize("S,B,R", [(4, 65536, 7), (16, 8192, 20), (25, 4096, 64), (9, 20000, 12)])
+@pytest.mark.parametrize("S,B,R", [(4, 65536, 7), (16, 8192, 20), (25, 4096, 64), (9, 20000, 12),
+                                   (4, 131072, 7), (4, 1 << 20, 7)])   # cfg4: per-GPU share at 8 GPUs, and whole
 def test_full_size_generate_replay_terminate(S, B, R):
-    """cfg2/cfg3/cfg5-per-GPU: generator -> replay the demo's own actions -> every game reaches
+    """cfg2/cfg3/cfg4/cfg5-per-GPU: generator -> replay the demo's own actions -> every game reaches
     zero exactly at the last step (generator, step, step_many and done agree)."""
     demos = SyntheticDemos(R, B, 1, S, DEV, seed=S)
     assert not bool(demos.overflow.any())
@@ -738,52 +739,6 @@ def test_maximum_action_counts(S, B):
         ops.step_many(padded(st), torch.zeros((B, TG_MAX_ACTIONS + 1, 3 * S), dtype=torch.int8, device=DEV))
 
 
-AB_SCRIPT = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from mat_mul_amd import ops
-from oracle import tensor_game as O
-rng = np.random.default_rng(1)
-for S, B, K in [(9, 9, 6), (16, 6, 5), (25, 3, 7)]:
-    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
-    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, K, 3 * S)).astype(np.int8)
-    t = ops.alloc_states(B, S, "cuda:0"); t.copy_(torch.from_numpy(st))
-    a = torch.from_numpy(ac).cuda()
-    w, wd, _ = O.step_i8(st, ac[:, 0])
-    o, d = ops.step(t, a[:, 0].contiguous())
-    assert np.array_equal(o.cpu().numpy(), w) and np.array_equal(d.cpu().numpy(), wd)
-    w, wds, _ = O.step_many_i8(st, ac)
-    o, ds = ops.step_many(t, a)
-    assert np.array_equal(o.cpu().numpy(), w) and np.array_equal(ds.cpu().numpy(), wds)
-    wk, wdn, wch, _ = O.expand_i8(st, ac)
-    k, dn, ch = ops.expand(t, a)
-    assert np.array_equal(k.cpu().numpy(), wk) and np.array_equal(dn.cpu().numpy(), wdn) and np.array_equal(ch.cpu().numpy(), wch)
-    assert np.array_equal(ops.gen_from_factors(a, S).cpu().numpy(), O.gen_from_factors_i8(ac)[0])
-    thr = O.categorical_thresholds((0.15, 0.7, 0.15))
-    P_o, _, _ = O.sample_basis(B, S, O.categorical_thresholds((0.05, 0.9, 0.05)), (-1, 0, 1), seed=4)
-    tok_o, tgt_o, ovf_o = O.gen_demos_i8(B, S, 40, thr, (-1, 0, 1), 1, seed=3, basis=P_o)
-    ovf = torch.zeros(B, dtype=torch.uint8, device="cuda:0")
-    tok, tgt = ops.gen_demos(B, S, 40, "cuda:0", seed=3, basis=torch.from_numpy(P_o.astype(np.int8)).cuda(), overflow=ovf)
-    assert np.array_equal(tok.cpu().numpy(), tok_o) and np.array_equal(tgt.cpu().numpy(), tgt_o)
-    assert np.array_equal(ovf.cpu().numpy(), ovf_o)
-print("AB_OK")
-'''
-
-
-@pytest.mark.parametrize("env_name", ["TG_FORCE_I32", "TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA", "TG_MFMA_MANY_ALWAYS"])
-def test_ab_switch_paths_stay_exact(env_name, tmp_path):
-    """The measurement switches (32-bit cursor kernels; packed chunks instead of rows) select
-    kernels that the default dispatch no longer uses -- they must stay bit-exact too."""
-    import os, subprocess, sys
-    from pathlib import Path
-    script = tmp_path / "ab.py"
-    script.write_text(AB_SCRIPT)
-    root = str(Path(__file__).resolve().parent.parent)
-    env = dict(os.environ, **{env_name: "1"})
-    res = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
-    assert res.returncode == 0 and "AB_OK" in res.stdout, res.stderr[-2000:]
-
-
 def test_randomized_differential():
     """Seeded random configurations -- S, batch, game stride padding, byte offset of the buffer,
     vocabulary, shift, action count, mode -- every one compared bit for bit with the oracle."""
@@ -937,46 +892,7 @@ def test_no_out_of_bounds_writes():
                 check_flat(scbuf, "emit_frames scalars")
 
 
-@pytest.mark.parametrize("S,B", [(4, 70), (9, 33), (16, 12), (25, 5), (6, 9), (16, 1)])
-def test_step_sparse_rollout_matches_dense(S, B):
-    """tg_step_sparse_i8 over a multi-step rollout: state, done and the carried nnz equal the oracle at every
-    step -- sparse, dense and wide-factor actions, games that terminate, games that overflow."""
-    rng = np.random.default_rng(S * 11 + B)
-    K = 9
-    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, K, 3 * S)).astype(np.int8)
-    ac[:, 3] = rng.integers(0, 3, size=(B, 3 * S))                       # a dense action
-    ac[1::3, 5] = rng.integers(-3, 6, size=ac[1::3, 5].shape)            # wide factors
-    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
-    st[::4] = O.gen_from_factors_i8(ac[::4, :4])[0]                      # these reach zero after step 3
-    st[2::5] = rng.choice([-128, 127, 0], size=st[2::5].shape)           # these overflow
-    for layout in ("padded", "packed"):
-        t = padded(st) if layout == "padded" else dev(st)
-        nnz = ops.done(t, want_nnz=True)[1]
-        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
-        cur, want_ovf = st.copy(), np.zeros(B, np.uint8)
-        for k in range(K):
-            cur, want_done, o = O.step_i8(cur, ac[:, k])
-            want_ovf |= o
-            out, done = ops.step_sparse(t, dev(ac[:, k]), nnz, overflow=ovf)
-            assert out.data_ptr() == t.data_ptr()
-            assert np.array_equal(host(t), cur), (S, layout, k)
-            assert np.array_equal(host(done), want_done), (S, layout, k)
-            assert np.array_equal(host(nnz), O.nnz_per_game(cur)), (S, layout, k)
-            assert np.array_equal(host(ovf), want_ovf), (S, layout, k)
-        assert want_ovf.any() or B == 1
-    env = TensorGameEnv(B, S, DEV, incremental=True)
-    env.reset(dev(st))
-    cur = st.copy()
-    for k in range(4):
-        cur, want_done, _ = O.step_i8(cur, ac[:, k])
-        state, done = env.step(dev(ac[:, k]))
-        assert np.array_equal(host(state), cur) and np.array_equal(host(done), want_done)
-        assert np.array_equal(host(env.nnz()), O.nnz_per_game(cur))
-    idx = [b for b in range(0, B, 4) if b % 5 != 2]                       # terminating games not overwritten above
-    assert host(env.done)[idx].all()
-
-
-@pytest.mark.parametrize("S,B,R", [(25, 512, 64), (16, 1024, 20), (4, 4096, 7)])
+@pytest.mark.parametrize("S,B,R", [(25, 512, 64), (16, 1024, 20), (4, 4096, 7), (25, 4096, 64)])
 def test_cfg5_generate_in_random_basis_then_replay(S, B, R):
     """BASELINE config 5 shape: targets generated in a random unimodular basis; replaying the EMITTED actions
     (any order) takes every game that did not overflow to zero, and the tensor-level change of basis of the
@@ -996,3 +912,143 @@ def test_cfg5_generate_in_random_basis_then_replay(S, B, R):
     moved = ops.change_basis(plain_tgt, P.to(torch.int32), overflow=ovf2)
     both = ok & ~ovf2.bool()
     assert torch.equal(moved[both], tgt[both])
+
+
+# ------------------------------------------------------------------ round-2 gap closers
+def test_expand_refuses_out_that_cannot_be_addressed_by_one_stride():
+    """out = big[:, :k] of a wider (B,k2,...) buffer cannot be addressed as base + (b*k+i)*stride; the
+    old code flattened it (a silent copy) and wrote through the original pointer with the copy's strides."""
+    B, S, k, k2 = 6, 4, 3, 5
+    st, ac = rand_case(np.random.default_rng(3), B, S, k=k)
+    big = ops.alloc_states(B * k2, S, DEV).unflatten(0, (B, k2))
+    with pytest.raises(mat_mul_amd.TensorGameError, match="evenly spaced"):
+        ops.expand(padded(st), dev(ac), out=big[:, :k])
+    # evenly spaced views are fine: every second slot of a wider buffer
+    wide = ops.alloc_states(B * k * 2, S, DEV)
+    out = wide[::2].unflatten(0, (B, k))
+    kids, dn, ch = ops.expand(padded(st), dev(ac), out=out)
+    wk, wdn, wch, _ = O.expand_i8(st, ac)
+    assert np.array_equal(host(kids), wk) and np.array_equal(host(dn), wdn) and np.array_equal(host(ch), wch)
+    assert not bool(wide[1::2].any())                       # the slots in between were not touched
+
+
+def test_sample_basis_refuses_values_that_overflow_int8():
+    """P = L @ U is emitted as int8; with |value| = 3 at S = 25 an entry can reach 225 and would wrap."""
+    with pytest.raises(mat_mul_amd.TensorGameError, match="S\\*v\\^2"):
+        ops.sample_basis(4, 25, DEV, values=(-3, 0, 3), probs=(0.1, 0.8, 0.1))
+    import ctypes as C
+    thr = O.categorical_thresholds((0.1, 0.8, 0.1))
+    val = np.array([-3, 0, 3], np.int8)
+    buf = torch.zeros((4, 3, 25, 25), dtype=torch.int8, device=DEV)
+    rc = mat_mul_amd._lib.lib.tg_sample_basis_i8(C.c_void_p(buf.data_ptr()), None, None, 4, 25, thr.ctypes.data_as(C.c_void_p),
+                                                 val.ctypes.data_as(C.c_void_p), 3, 0, 0, None)
+    assert rc == -1 and b"S*v^2" in mat_mul_amd._lib.lib.tg_last_error()
+    with pytest.raises(ValueError):
+        O.sample_basis(4, 25, thr, (-3, 0, 3), seed=0)
+    P, L, U = ops.sample_basis(8, 9, DEV, values=(-3, 0, 3), probs=(0.1, 0.8, 0.1), seed=2, want_factors=True)  # 9*9 <= 127
+    Po, Lo, Uo = O.sample_basis(8, 9, thr, (-3, 0, 3), seed=2)
+    assert np.array_equal(host(P), Po) and np.array_equal(host(L), Lo) and np.array_equal(host(U), Uo)
+
+
+@pytest.mark.parametrize("S,B", [(4, 1000), (9, 77), (16, 33), (25, 9), (5, 3), (32, 2)])
+def test_copy_states(S, B):
+    """tg_copy_i8: every layout pair (padded / packed / byte-offset), padding bytes untouched, env.snapshot()."""
+    rng = np.random.default_rng(S)
+    st = rng.integers(-128, 128, size=(B, S, S, S)).astype(np.int8)
+    n = S ** 3
+    src_p, src_k = padded(st), dev(st)
+    off = torch.zeros(B * n + 3, dtype=torch.int8, device=DEV)[3:].view(B, S, S, S)  # byte-offset, packed
+    off.copy_(src_k)
+    for src in (src_p, src_k, off):
+        for mk in ("padded", "packed", "wide"):
+            if mk == "padded":
+                dst = ops.alloc_states(B, S, DEV)
+            elif mk == "packed":
+                dst = torch.zeros((B, S, S, S), dtype=torch.int8, device=DEV)
+            else:
+                raw = torch.full((B, n + 48), 77, dtype=torch.int8, device=DEV)
+                dst = raw[:, :n].unflatten(1, (S, S, S))
+            out = ops.copy_states(src, dst)
+            assert out.data_ptr() == dst.data_ptr() and np.array_equal(host(dst), st), (S, mk)
+            if mk == "wide":
+                assert bool((raw[:, n:] == 77).all())       # padding between games is never written
+    env = TensorGameEnv(B, S, DEV)
+    env.reset(src_k)
+    snap = env.snapshot()
+    env.step(dev(rng.integers(0, 3, size=(B, 3 * S)).astype(np.int8)))
+    assert np.array_equal(host(snap), st)                    # the snapshot is not a view of the live state
+    assert ops.copy_states(ops.alloc_states(0, S, DEV)).shape[0] == 0
+
+
+def test_demo_io_round_trip_from_gpu(tmp_path):
+    """N4 on the GPU: demos generated on the device -> SyntheticDemos.save / load_packed, and
+    export_reference_layout / import_reference_layout (the reference's per-demo files, datasets.py:62-69) ->
+    the bytes come back, and replaying the re-imported actions on the re-imported targets reaches zero."""
+    from mat_mul_amd import demo_io
+    for S, B, R in [(4, 300, 7), (16, 40, 20), (25, 12, 64)]:
+        demos = SyntheticDemos(R, B, 1, S, DEV, seed=100 + S, game_id_offset=17)
+        f = tmp_path / f"demos_{S}.tgd"
+        demos.save(f)
+        tok, tgt, meta = demo_io.load_packed(f, device=DEV)
+        assert meta == {"B": B, "R": R, "S": S, "shift": 1, "seed": 100 + S, "game_id_offset": 17}
+        assert torch.equal(tok, demos.action_seq) and torch.equal(tgt, demos.target_tensor)
+        d = tmp_path / f"ref_{S}"
+        assert demos.export_reference_layout(d) == B
+        seq0 = torch.load(d / "action_seq_17.pt")            # the reference's layout: list of R int64 (3S,) + fp32 (S,S,S)
+        t0 = torch.load(d / "target_tensor_17.pt")
+        assert isinstance(seq0, list) and len(seq0) == R and seq0[0].dtype == torch.int64 and tuple(seq0[0].shape) == (3 * S,)
+        assert t0.dtype == torch.float32 and tuple(t0.shape) == (S, S, S)
+        tok2, tgt2 = demo_io.import_reference_layout(d, B, start_index=17)
+        assert torch.equal(tok2.to(DEV), demos.action_seq) and torch.equal(tgt2.to(DEV), demos.target_tensor)
+        final, done_step = ops.step_many(padded(tgt2.numpy()), tok2.to(DEV))
+        assert not bool(final.any()) and bool((done_step >= 0).all())
+
+
+def test_integration_md_stub_runs_against_strassen_golden(golden, tmp_path):
+    """INTEGRATION.md's ctypes stub -- the reference-side binding for act.py:183 / utils.py:181 -- extracted
+    verbatim from the document and executed: the Strassen replay must reproduce the recorded reference states."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    md = (root / "INTEGRATION.md").read_text()
+    code = re.search(r"```python\n(.*?)```", md, flags=re.S).group(1)
+    assert "tensor_game_ffi.py" in code and "def step(" in code
+    code = code.replace('C.CDLL("libtensorgame.so")', f'C.CDLL({str(mat_mul_amd._lib.LIB_PATH)!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    g = golden("strassen")
+    state = dev(g["replay"][0][None].astype(np.int8)).contiguous()
+    done = torch.zeros(1, dtype=torch.uint8, device=DEV)
+    for k in range(7):
+        ns["step"](state, dev(g["tokens"][k][None].astype(np.int8)), done)
+        torch.cuda.synchronize()
+        assert np.array_equal(host(state)[0], g["replay"][k + 1]) and int(done[0]) == int(g["done"][k + 1])
+    # the stub's expand binding: children of the start state for the first two Strassen actions
+    lib = ns["lib"]
+    par = dev(g["replay"][0][None].astype(np.int8)).contiguous()
+    acts = dev(g["tokens"][:2][None].astype(np.int8)).contiguous()
+    kids = torch.zeros((2, 4, 4, 4), dtype=torch.int8, device=DEV)
+    dn = torch.zeros(2, dtype=torch.uint8, device=DEV)
+    ch = torch.zeros(2, dtype=torch.uint8, device=DEV)
+    ns["_check"](lib.tg_expand_i8(par.data_ptr(), kids.data_ptr(), acts.data_ptr(), dn.data_ptr(), ch.data_ptr(), None,
+                                  1, 4, 2, 64, 64, 1, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    wk, wdn, wch, _ = O.expand_i8(g["replay"][0][None].astype(np.int8), g["tokens"][:2][None].astype(np.int8))
+    assert np.array_equal(host(kids), wk[0]) and np.array_equal(host(dn), wdn[0]) and np.array_equal(host(ch), wch[0])
+
+
+def test_bench_two_ranks_self_launched_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` with no launcher: bench.py starts its own ranks (torch.distributed.run children).
+    On the one-GPU box both ranks share the GPU and the control plane is gloo (TG_BENCH_BACKEND)."""
+    import json, os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TG_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--global-batch", "131072", "--no-also"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 20 and out["samples"] == 9
+    assert out["config"]["global_batch"] == 131072 and out["config"]["batch_per_gpu"] == 65536
+    assert out["value"] > 1e9 and 0 < out["roofline"]["frac"] <= 1.0
