@@ -143,6 +143,7 @@ class StepTimer:
         self.launch = ops.prepare_step(self.state, sched, self.done, self.ovf, shift=shift)
         self.pos = 0
         self.graphs = {}
+        self.lead_in = 8  # launches in front of the K timed ones in the differential event measurement
 
     def eager(self, n):
         for _ in range(n):
@@ -228,16 +229,36 @@ class StepTimer:
             sync()
         self._rewind(p0)
         torch.cuda.synchronize(self.dev)
-        # kernel time: HIP events on the launch stream around each K-step run, no host sync between samples
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(samples + 1)]
-        self.run_k(K)  # lead-in run: the first timed sample then starts behind work already in flight
-        for i in range(samples + 1):
-            evs[i].record()
-            if i < samples:
-                self.run_k(K)
+        # kernel time.  One replay of a hipGraph costs a fixed ~13 us on top of its nodes (ROCm 7.2; measured by
+        # tools/graph_overhead_probe.py, profiles/r02_graph_replay_overhead.txt: 17.5 us for 1 node, 62.8 us for 20,
+        # 5081 us for 2016), also when replays are enqueued back to back -- runtime submit cost, not kernel time.  So
+        # the K launches are timed DIFFERENTIALLY, with HIP events on the launch stream and no host sync in between:
+        # T(m lead-in launches + the K launches, one run) - T(m launches, one run), each run paying that fixed cost once.
+        m = self.lead_in
+        seq = []
+        for _ in range(samples):
+            seq += [m + K, m]
+
+        def run_seq(evs):
+            self.run_k(m)  # the first timed run starts behind work already in flight
+            for i, n in enumerate(seq):
+                if evs:
+                    evs[i].record()
+                self.run_k(n)
+            if evs:
+                evs[len(seq)].record()
+
+        run_seq(None)  # rehearsal: captures / uploads every (phase, length) graph of the sequence
+        self._rewind(p0)
         torch.cuda.synchronize(self.dev)
-        event_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(samples)]
-        return {"wall_s": walls, "event_ms": event_ms, "ok": self.check()}
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(seq) + 1)]
+        run_seq(evs)
+        torch.cuda.synchronize(self.dev)
+        t = [evs[i].elapsed_time(evs[i + 1]) for i in range(len(seq))]
+        event_ms = [t[2 * i] - t[2 * i + 1] for i in range(samples)]          # exactly K launches each
+        replay_ms = [t[2 * i] for i in range(samples)]                         # one run of m + K launches, as it is
+        return {"wall_s": walls, "event_ms": event_ms, "ok": self.check(), "lead_in": m,
+                "run_ms_with_lead_in": replay_ms, "run_ms_lead_in_only": [t[2 * i + 1] for i in range(samples)]}
 
 
 def copy_ceiling_gbps(B, S, dev, K=64, samples=5):
@@ -285,7 +306,7 @@ def measured_traffic(B, S, kernel):
     return None, None
 
 
-def roofline(B, S, K, event_ms_samples, needed_bytes=None, copy=None, footprint=None):
+def roofline(B, S, K, event_ms_samples, needed_bytes=None, copy=None, footprint=None, res=None):
     """The roofline object of one workload.  `frac` = needed bytes / median launch time / HBM peak: the bytes the
     launch must move (never more than SURVEY's algorithmic figure), so it cannot be inflated by stores the kernel
     skips; `frac_algorithmic` prices SURVEY's 2S^3+3S+1 unconditionally and CAN exceed what the memory system
@@ -307,8 +328,16 @@ def roofline(B, S, K, event_ms_samples, needed_bytes=None, copy=None, footprint=
            "regime": ("cache-resident: %.0f MiB of states < 256 MiB Infinity Cache, HBM itself is not exercised"
                       % (footprint / 2 ** 20)) if footprint < INFINITY_CACHE_BYTES
            else "hbm-streaming: %.0f MiB of states per launch" % (footprint / 2 ** 20),
-           "method": "median over the samples of (HIP events around one replay of the K-launch hipGraph, replays "
-                     "enqueued back to back) / K; frac = needed bytes per launch / that time / peak"}
+           "method": "HIP events on the launch stream, no host sync inside the pass: per sample T(run of m lead-in + K "
+                     "launches) - T(run of m launches), median over the samples, / K -- the fixed cost of a hipGraph "
+                     "replay (~13 us, runtime submit) cancels; frac = needed bytes per launch / that time / peak"}
+    if res is not None and "run_ms_with_lead_in" in res:
+        m = res["lead_in"]
+        out["lead_in_launches"] = m
+        out["run_us_median"] = {"m_plus_K_launches": round(statistics.median(res["run_ms_with_lead_in"]) * 1e3, 2),
+                                "m_launches": round(statistics.median(res["run_ms_lead_in_only"]) * 1e3, 2)}
+        out["graph_replay_fixed_cost_us"] = round(
+            statistics.median(res["run_ms_lead_in_only"]) * 1e3 - m * per_launch_s * 1e6, 2)
     if copy is not None:
         out["copy_ceiling_GBps"], out["copy_launch_us"] = copy
         out["frac_of_copy_ceiling"] = round(out["achieved"] / copy[0], 4) if copy[0] else None
@@ -498,7 +527,7 @@ def main(argv=None):
                        "timing": f"{args.samples} samples of exactly {args.steps} steps, each bracketed by barrier + "
                                  f"synchronize, max over ranks per sample, median over samples",
                        "wall_us_per_sample": [round(w * 1e6, 1) for w in walls]},
-            "roofline": roofline(B, S, args.steps, res["event_ms"], need, copy),
+            "roofline": roofline(B, S, args.steps, res["event_ms"], need, copy, res=res),
         }
         if world > 1 and scaling == "strong" and not args.no_also:
             # the same GLOBAL batch on ONE GPU (rank 0 alone, after the timed region): the denominator of the
