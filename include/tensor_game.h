@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 1
+#define TG_ABI_VERSION 2 /* 2: the generator draws 16-bit uniforms (8 per Philox block); tg_copy_i8 */
 #define TG_MAX_S 32
 #define TG_MAX_VALUES 8 /* categories of the factor distribution */
 
@@ -135,9 +135,12 @@ int tg_gen_from_factors_i8(const int8_t* actions, int8_t* target_out, uint8_t* o
  * target_out[b] = sum of the R rank-1 terms.  Replaces create_synthetic_demo (utils.py:203-233) /
  * SyntheticDemoDataset._create_synthetic_demos (datasets.py:124-142) + _factor_sample (:155-158).
  * RNG: Philox-4x32-10, key = seed, counter = (g_lo, g_hi, 3*r+x, attempt<<8 | block) -- keyed by
- * the GLOBAL game id, so output does not depend on how games are sharded over GPUs.
+ * the GLOBAL game id, so output does not depend on how games are sharded over GPUs.  One block
+ * yields EIGHT 16-bit draws: element 8*block + 2*m + half of the vector comes from output word m
+ * (0..3), low half first.
  * values: host int8[n_values]; thresholds: host uint32[n_values-1], ascending cdf * 2^32:
- * a 32-bit draw d selects values[#{t : d >= t}].
+ * a 16-bit draw d selects values[#{t : d * 2^16 >= t}] (every probability is honoured to within
+ * 2^-16; tg_sample_basis_i8 draws 32-bit uniforms: d selects values[#{t : d >= t}]).
  * basis (may be NULL): int8 (B,3,S,S) per-game matrices (A,B,C); when given, every term is
  * emitted in the new basis: (u,v,w) -> (Au,Bv,Cw) (not in the reference). */
 int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, int64_t B, int S,

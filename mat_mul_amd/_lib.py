@@ -11,7 +11,7 @@ from pathlib import Path
 AB_VARIANT = os.environ.get("TG_LIB_VARIANT", "") == "ab"
 LIB_PATH = Path(__file__).resolve().parent / "lib" / ("libtensorgame_ab.so" if AB_VARIANT else "libtensorgame.so")
 
-TG_ABI_VERSION = 1
+TG_ABI_VERSION = 2
 TG_MAX_S = 32
 TG_MAX_VALUES = 8
 TG_MAX_ACTIONS = 4096

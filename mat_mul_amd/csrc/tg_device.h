@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/tensor_game.h"
+
 // Measurement switches (environment variables) exist only in the A/B build (mat_mul_amd/build.py, ab=True);
 // in the product library TG_SWITCH() is the constant false and no entry point reads the environment.
 #ifdef TG_AB_SWITCHES
@@ -76,6 +78,69 @@ __device__ __forceinline__ bool team_any(bool p) {
     const int base = lane & ~(TS - 1);
     return ((m >> base) & ((1ull << TS) - 1ull)) != 0;
   }
+}
+
+// ---- packed int16 helpers used by several kernel families ------------------------------------
+__device__ __forceinline__ uint32_t pk_sub_u16_sat(uint32_t a, uint32_t b) {  // max(a - b, 0) per half
+  uint32_t d;
+  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {  // low 16 bits of a*b + c per half
+  uint32_t d;
+  asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// ---- the factor distribution of the generator (host-filled, passed by value) ----------------
+// The basis sampler draws 32-bit uniforms against `thr`.  The factor generator draws SIXTEEN-bit uniforms,
+// eight per Philox block: a draw d16 selects val[#{t : d16 * 2^16 >= thr[t]}], i.e. d16 is compared with
+// thr16[t] = ceil(thr[t] / 2^16) in [0, 65536].  For the packed evaluation (two draws per dword) the
+// thresholds that are always true (thr16 == 0) are folded into `base16` and those never true (65536) are
+// dropped: value = base + sum_{t < nthr} [d16 >= c16[t] + 1] * delta16[t], all int16 replicated in both halves.
+struct Dist {
+  uint32_t thr[TG_MAX_VALUES - 1];
+  int8_t val[TG_MAX_VALUES];
+  int nv;
+  uint32_t thr16[TG_MAX_VALUES - 1];
+  int nthr;
+  uint32_t c16[TG_MAX_VALUES - 1];
+  uint32_t delta16[TG_MAX_VALUES - 1];
+  uint32_t base16;
+};
+
+// one 16-bit draw -> value (scalar form; gen_tokens_kernel)
+__device__ __forceinline__ int draw_value16(uint32_t d16, const Dist& D) {
+  if (D.nv == 3) {  // the reference's vocabulary (-1,0,1): two compares, two selects (wave-uniform branch)
+    const int v = d16 >= D.thr16[0] ? D.val[1] : D.val[0];
+    return d16 >= D.thr16[1] ? D.val[2] : v;
+  }
+  int idx = 0;
+#pragma unroll
+  for (int t = 0; t < TG_MAX_VALUES - 1; ++t) idx += (t < D.nv - 1) && (d16 >= D.thr16[t]);
+  int v = D.val[0];
+#pragma unroll
+  for (int t = 1; t < TG_MAX_VALUES; ++t) v = (idx == t) ? D.val[t] : v;
+  return v;
+}
+
+// two 16-bit draws (the halves of one Philox output word) -> two int16 values, 3 packed ops per threshold
+__device__ __forceinline__ uint32_t draw_pair16(uint32_t w, const Dist& D) {
+  uint32_t v = D.base16;
+  if (D.nthr == 2) {  // wave-uniform: the ternary vocabulary
+    v = pk_mad_u16(pk_min_u16(pk_sub_u16_sat(w, D.c16[0]), 0x00010001u), D.delta16[0], v);
+    v = pk_mad_u16(pk_min_u16(pk_sub_u16_sat(w, D.c16[1]), 0x00010001u), D.delta16[1], v);
+    return v;
+  }
+#pragma unroll
+  for (int t = 0; t < TG_MAX_VALUES - 1; ++t)
+    if (t < D.nthr) v = pk_mad_u16(pk_min_u16(pk_sub_u16_sat(w, D.c16[t]), 0x00010001u), D.delta16[t], v);
+  return v;
 }
 
 // ---- Philox-4x32-10 (Salmon et al. SC'11); bit-identical to oracle/tensor_game.py -----------

@@ -15,15 +15,15 @@
 #include "tg_device.h"
 
 int tg_internal_fail(int code, const char* fmt, ...);  // tg_kernels.hip
+namespace tg { struct Dist; }
+// the generator in one kernel (tg_genfused.h, launched from tg_kernels.hip): 1 = launched, 0 = not applicable
+int tg_internal_gen_fused(int8_t* target, int8_t* actions, uint8_t* overflow, const int8_t* basis, int64_t B, int S,
+                          int R, const tg::Dist& D, int shift, uint64_t seed, uint64_t gid0, int64_t stride,
+                          hipStream_t st);
 
 namespace tg {
 
-struct Dist {
-  uint32_t thr[TG_MAX_VALUES - 1];
-  int8_t val[TG_MAX_VALUES];
-  int nv;
-};
-
+// one 32-bit draw -> value (the basis sampler: one draw per matrix cell)
 __device__ __forceinline__ int draw_value(uint32_t d, const Dist& D) {
   if (D.nv == 3) {  // the reference's vocabulary (-1,0,1): two compares, two selects (wave-uniform branch)
     const int v = d >= D.thr[0] ? D.val[1] : D.val[0];
@@ -42,7 +42,8 @@ constexpr uint32_t kStreamBasis = 0x80000000u;
 constexpr uint32_t kMaxAttempts = 1u << 16;
 
 // Factor vectors (game b, term r, x in {u,v,w}).  Counter = (gid_lo, gid_hi, 3r+x,
-// attempt<<8 | block), key = seed: identical to oracle/tensor_game.py::_draw_vector.
+// attempt<<8 | block), key = seed; a block yields eight 16-bit draws (elements 8 block + 2 word + half):
+// identical to oracle/tensor_game.py::_draw_vector.
 // ST > 0: S is a compile-time constant, the vector lives in registers.
 // Rejection sampling diverges: at S=4 a vector is rejected with probability 0.24, and a wavefront
 // that gives each lane ONE vector runs max-over-64-lanes attempts (about 3.9 instead of 1.3).  So a
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void gen_tokens_kernel(int8_t* actions_out,
                                                             int Srt, int R, Dist D, int shift, uint64_t seed,
                                                             uint64_t gid0, const int8_t* basis, int vec16) {
   constexpr int SMAX = ST ? ST : TG_MAX_S;
-  constexpr int NBLK = (SMAX + 3) / 4;
+  constexpr int NBLK = (SMAX + 7) / 8;  // one Philox block = eight 16-bit draws
   __shared__ __attribute__((aligned(16))) int8_t stage[kBlock * M * SMAX];
   const int S = ST ? ST : Srt;
   const int64_t nvec = B * R * 3;
@@ -81,16 +82,16 @@ __global__ __launch_bounds__(kBlock) void gen_tokens_kernel(int8_t* actions_out,
       bool any = false;
 #pragma unroll
       for (int q = 0; q < NBLK; ++q) {
-        if (4 * q < S) {
+        if (8 * q < S) {
           const U4 o = philox4x32_10(U4{static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
                                         static_cast<uint32_t>(sub), (attempt << 8) | static_cast<uint32_t>(q)},
                                      k0, k1);
           const uint32_t d[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int e = 4 * q + t;
+          for (int t = 0; t < 8; ++t) {  // element 8q + t: word t/2, low half first
+            const int e = 8 * q + t;
             if (e < SMAX) {
-              f[e] = (e < S) ? draw_value(d[t], D) : 0;
+              f[e] = (e < S) ? draw_value16((d[t >> 1] >> (16 * (t & 1))) & 0xFFFFu, D) : 0;
               any |= f[e] != 0;
             }
           }
@@ -500,6 +501,35 @@ int make_dist(const char* fn, const uint32_t* thresholds, const int8_t* values, 
   }
   if (!nonzero) return tg_internal_fail(TG_ERR_INVALID, "%s: distribution never draws a non-zero value", fn);
   D->nv = nv;
+  // the 16-bit form of the factor generator: thr16 = ceil(thr / 2^16); always-true thresholds fold into the base
+  // value, never-true ones are dropped
+  int base = 0;
+  D->nthr = 0;
+  for (int t = 0; t < TG_MAX_VALUES - 1; ++t) {
+    D->thr16[t] = t < nv - 1 ? static_cast<uint32_t>((static_cast<uint64_t>(thresholds[t]) + 0xFFFFu) >> 16) : 0x10000u;
+    D->c16[t] = D->delta16[t] = 0;
+  }
+  for (int t = 0; t < nv - 1; ++t) {
+    if (D->thr16[t] == 0) {
+      base = t + 1;
+    } else if (D->thr16[t] <= 0xFFFFu) {
+      const uint32_t c = D->thr16[t] - 1, dl = static_cast<uint16_t>(static_cast<int>(values[t + 1]) - static_cast<int>(values[t]));
+      D->c16[D->nthr] = c | (c << 16);
+      D->delta16[D->nthr] = dl | (dl << 16);
+      ++D->nthr;
+    }
+  }
+  {
+    const uint32_t b16 = static_cast<uint16_t>(static_cast<int>(values[base]));
+    D->base16 = b16 | (b16 << 16);
+  }
+  bool nonzero16 = false;  // the same question at 16-bit resolution: is some non-zero value still reachable?
+  for (int t = 0; t < nv; ++t) {
+    const uint32_t lo = t == 0 ? 0 : D->thr16[t - 1], hi = t == nv - 1 ? 0x10000u : D->thr16[t];
+    if (values[t] != 0 && hi > lo) nonzero16 = true;
+  }
+  if (!nonzero16)
+    return tg_internal_fail(TG_ERR_INVALID, "%s: at the generator's 16-bit resolution the distribution never draws a non-zero value", fn);
   return TG_OK;
 }
 
@@ -530,9 +560,14 @@ int tg_gen_demos_i8(int8_t* target_out, int8_t* actions_out, uint8_t* overflow, 
   if (int rc = make_dist(fn, thresholds, values, n_values, &D)) return rc;
   if (B == 0) return TG_OK;
   if (!target_out || !actions_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // S = 9 / 16 / 25: draw, change of basis, accumulation and both outputs in ONE kernel (tg_genfused.h)
+  if (int rc = tg_internal_gen_fused(target_out, actions_out, overflow, basis, B, S, R, D, shift, seed, game_id_offset,
+                                     game_stride_bytes, st))
+    return rc < 0 ? rc : TG_OK;
+  // otherwise: tokens (+ change of basis on the tokens), then the accumulation of tg_gen_from_factors_i8
   const int64_t nvec = B * R * 3;
   const int vec16 = (reinterpret_cast<uintptr_t>(actions_out) & 15) == 0;
-  hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();
 #define TG_GT(ST, M)                                                                                      \
   do {                                                                                                    \

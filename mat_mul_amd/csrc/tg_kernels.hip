@@ -430,6 +430,7 @@ __global__ __launch_bounds__(kBlock) void team_kernel(ApplyArgs a) {
 #include "tg_packed.h"
 #include "tg_rows.h"
 #include "tg_mfma.h"
+#include "tg_genfused.h"
 
 // =============================================================================================
 // S = 4 in registers: 4 lanes per game, lane q owns slice i = q (16 bytes = one dwordx4).
@@ -1199,6 +1200,55 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
 }
 
 }  // namespace
+
+// The generator in one kernel (tg_genfused.h); called by tg_gen_demos_i8 (tg_gen.hip).
+// Returns 1 = launched, 0 = not applicable (the caller takes the token kernel + tg_gen_from_factors_i8), < 0 = error.
+int tg_internal_gen_fused(int8_t* target, int8_t* actions, uint8_t* overflow, const int8_t* basis, int64_t B, int S,
+                          int R, const tg::Dist& D, int shift, uint64_t seed, uint64_t gid0, int64_t stride,
+                          hipStream_t st) {
+  using namespace tg;
+  const char* fn = "tg_gen_demos_i8";
+  if (TG_SWITCH("TG_NO_FUSED_GEN") || TG_SWITCH("TG_NO_MFMA") || TG_SWITCH("TG_FORCE_I32")) return 0;
+  if (!(S == 9 || S == 16 || S == 25) || R > 256 || B == 0) return 0;
+  if (!aligned16(target) || stride % 16 != 0) return 0;
+  if (!basis) {  // the drawn values are the factors: u * v must fit a byte product, tokens must fit int8
+    for (int t = 0; t < D.nv; ++t) {
+      const int v = D.val[t];
+      if (v > 11 || v < -11 || v + shift > 127 || v + shift < -128) return 0;
+    }
+  }
+  const int Rp = (R + 31) & ~31;
+  GenArgs ga{target, actions, overflow, basis, B, stride, seed, gid0, R, shift, D};
+#define TG_GF_K(S_, KS_, BAS_)                                                                     \
+  do {                                                                                             \
+    const int ldsb = genfused_lds_bytes<S_>(Rp, R);                                                \
+    static OccupancySlots occ;                                                                     \
+    const int64_t resident = static_cast<int64_t>(resident_per_cu(gen_fused_kernel<S_, KS_, BAS_>, ldsb, occ)) * device_cu_count(); \
+    const int64_t per_wg = (B + resident - 1) / resident;                                          \
+    const int64_t grid = (B + per_wg - 1) / per_wg;                                                \
+    (void)hipGetLastError();                                                                       \
+    hipLaunchKernelGGL((gen_fused_kernel<S_, KS_, BAS_>), dim3((unsigned)grid), dim3(kBlock), ldsb, st, ga, Rp); \
+    if (int rc = check_launch(fn)) return rc;                                                      \
+    return 1;                                                                                      \
+  } while (0)
+#define TG_GF(S_)                                                                                  \
+  do {                                                                                             \
+    if (basis) {                                                                                   \
+      if (Rp == 32) TG_GF_K(S_, 1, true);                                                          \
+      if (Rp == 64) TG_GF_K(S_, 2, true);                                                          \
+      TG_GF_K(S_, 0, true);                                                                        \
+    } else {                                                                                       \
+      if (Rp == 32) TG_GF_K(S_, 1, false);                                                         \
+      if (Rp == 64) TG_GF_K(S_, 2, false);                                                         \
+      TG_GF_K(S_, 0, false);                                                                       \
+    }                                                                                              \
+  } while (0)
+  if (S == 9) TG_GF(9);
+  if (S == 16) TG_GF(16);
+  TG_GF(25);
+#undef TG_GF
+#undef TG_GF_K
+}
 
 extern "C" {
 

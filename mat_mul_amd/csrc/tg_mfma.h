@@ -72,103 +72,42 @@ __device__ __forceinline__ v4i bytemul16(const v4i a, const v4i b) {
 
 struct __attribute__((packed)) UnalignedU32 { uint32_t v; };  // gfx950 LDS takes unaligned dwords (ds_write_b32)
 
-// KS: k-steps of 32 actions known at compile time (1 or 2: R <= 64), 0 = run-time Rp / 32.
-template <int S, int KS>
-__global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) {
-  using G = MGeo<S>;
-  extern __shared__ __attribute__((aligned(16))) uint8_t mfma_smem[];
-  if constexpr (KS != 0) Rp = 32 * KS;
-  const int RS = Rp + 16;  // row stride of T: a multiple of 16 (ds_read_b128), 5 bank quads apart at Rp = 64
-  int8_t* const T = reinterpret_cast<int8_t*>(mfma_smem);
-  uint8_t* const img = mfma_smem + G::TROWS * RS;
-  uint8_t* const flags = img + G::IMG + 16;  // the last column's closing dword may spill <= 3 bytes past N
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 31, h = lane >> 5;
-  const int R = a.nact;
-
-  // rows l >= S of W never receive a factor: zero them once, so that the unused rows of D are zero
-  for (int e = tid; e < (32 - S) * RS; e += kBlock) T[(3 * S) * RS + e] = 0;
-
-  // staging role: lane = (token position x, one of NRG groups of actions); each trip handles 4 actions
-  constexpr int NRG = kBlock / G::A3;
-  constexpr int TB = 6;  // trips per batch: every byte load of a batch is in flight before one is used
-  const int sx = tid % G::A3, srg = tid / G::A3;
-  const int slo = sx < 2 * S ? -G::UVLIM : -128, shi = sx < 2 * S ? G::UVLIM : 127;
-
-  // tile role: this wavefront's column tiles are the same for every game
-  constexpr int NW = kBlock / 64, TPW = (G::NT + NW - 1) / NW;
+// ---- the tile phase shared by genf_mfma_kernel and gen_fused_kernel (tg_genfused.h) -----------------------------
+// Which column tiles a wavefront owns, and where its lanes read their fragments: the same for every game.
+template <int S>
+struct TileMap {
+  static constexpr int NW = kBlock / 64, TPW = (MGeo<S>::NT + NW - 1) / NW;
   int uoff[TPW], voff[TPW], ncol[TPW];
+  int woff;
+};
+
+template <int S>
+__device__ __forceinline__ void make_tile_map(TileMap<S>& tm, int RS, int wave, int col, int h) {
+  using G = MGeo<S>;
+  constexpr int NW = TileMap<S>::NW, TPW = TileMap<S>::TPW;
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
     const int n = 32 * (wave + NW * k) + col;
     const int nn = n < G::S2 ? n : G::S2 - 1;  // columns past S^2 shadow the last one; never stored
     const int i = nn / S, j = nn - i * S;
-    uoff[k] = i * RS + 16 * h;
-    voff[k] = (S + j) * RS + 16 * h;
-    ncol[k] = n < G::S2 ? n : -1;
+    tm.uoff[k] = i * RS + 16 * h;
+    tm.voff[k] = (S + j) * RS + 16 * h;
+    tm.ncol[k] = n < G::S2 ? n : -1;
   }
-  const int woff = (2 * S + col) * RS + 16 * h;
+  tm.woff = (2 * S + col) * RS + 16 * h;
+}
 
-  // Token fetch and staging.  Buffer loads: one VGPR of lane offset + immediates instead of 24 64-bit addresses,
-  // and rows r >= R fall outside num_records (they read as 0), so no clamping.  fetch() only issues the loads of
-  // one batch (TB trips of 4 actions); commit() turns a batch into factors, checks their range and writes T.
-  auto fetch = [&](int64_t gg, int rb, int (&f)[TB][4]) {
-    const __amdgpu_buffer_rsrc_t tok = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int8_t*>(a.actions + gg * R * G::A3), 0, R * G::A3, 0x00027000);
-#pragma unroll
-    for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = rb + 4 * NRG * tb + t;
-        f[tb][t] = static_cast<int8_t>(__builtin_amdgcn_raw_buffer_load_b8(tok, sx + r * G::A3, 0, 0));
-      }
-  };
-  auto commit = [&](int rb, int (&f)[TB][4], int& big) {
-#pragma unroll
-    for (int tb = 0; tb < TB; ++tb) {
-      const int r0 = rb + 4 * NRG * tb;
-      if (r0 < Rp) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          f[tb][t] = (r0 + t < R) ? f[tb][t] - a.shift : 0;
-          big |= (f[tb][t] < slo) | (f[tb][t] > shi);
-        }
-        *reinterpret_cast<uint32_t*>(T + sx * RS + r0) = pack4(f[tb][0], f[tb][1], f[tb][2], f[tb][3]);
-      }
-    }
-  };
-  // When one batch covers all the actions (R <= 4 NRG TB), the NEXT game's tokens are fetched right after this
-  // game's staging barrier and stay in registers through the tile phase: the memory latency (about a quarter of
-  // a game's time in this kernel) disappears behind the arithmetic.
-  const bool one_batch = Rp <= 4 * NRG * TB;  // uniform
-  int pf[TB][4];
-  if (one_batch && srg < NRG && static_cast<int64_t>(blockIdx.x) < a.B) fetch(blockIdx.x, 4 * srg, pf);
-
-  for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
-    // ---- 1. factors of this game, transposed into LDS (4 actions = one dword); range check; r >= R -> 0 ----
-    int big = 0;
-    if (srg < NRG) {
-      if (one_batch) {
-        commit(4 * srg, pf, big);
-      } else {
-        for (int rb = 4 * srg; rb < Rp; rb += 4 * NRG * TB) {
-          int f[TB][4];
-          fetch(g, rb, f);
-          commit(rb, f, big);
-        }
-      }
-    }
-    const bool too_big = __syncthreads_or(big);
-    if (one_batch && srg < NRG && g + gridDim.x < a.B) fetch(g + gridDim.x, 4 * srg, pf);
-    if (too_big) {  // workgroup-uniform; rare: exact byte-wise form
-      note_fallback();
-      slow_game<GENF>(a, g, flags);
-      __syncthreads();
-      continue;
-    }
-
-    // ---- 2. column tiles on the matrix cores, two at a time ----
-    int hi = 0, lo = 0;  // running max / min of every result of this lane
+// All column tiles of one game: T (transposed factors, rows of RS = Rp + 16 bytes) -> the dense S^3 byte image `img`.
+// hi / lo: running max / min of every int32 result of this lane (the int8 range check).
+template <int S, int KS>
+__device__ __forceinline__ void accumulate_tiles(const int8_t* T, uint8_t* img, int Rp, const TileMap<S>& tm, int wave,
+                                                 int col, int h, int& hi, int& lo) {
+  using G = MGeo<S>;
+  constexpr int NW = TileMap<S>::NW, TPW = TileMap<S>::TPW;
+  const int (&uoff)[TPW] = tm.uoff;
+  const int (&voff)[TPW] = tm.voff;
+  const int (&ncol)[TPW] = tm.ncol;
+  const int woff = tm.woff;
     v4i wa[KS ? KS : 1];
 #pragma unroll
     for (int k = 0; k < KS; ++k) wa[k] = *reinterpret_cast<const v4i*>(T + woff + 32 * k);
@@ -246,6 +185,96 @@ __global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) 
         }
       }
     }
+}
+
+// KS: k-steps of 32 actions known at compile time (1 or 2: R <= 64), 0 = run-time Rp / 32.
+template <int S, int KS>
+__global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) {
+  using G = MGeo<S>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t mfma_smem[];
+  if constexpr (KS != 0) Rp = 32 * KS;
+  const int RS = Rp + 16;  // row stride of T: a multiple of 16 (ds_read_b128), 5 bank quads apart at Rp = 64
+  int8_t* const T = reinterpret_cast<int8_t*>(mfma_smem);
+  uint8_t* const img = mfma_smem + G::TROWS * RS;
+  uint8_t* const flags = img + G::IMG + 16;  // the last column's closing dword may spill <= 3 bytes past N
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int R = a.nact;
+
+  // rows l >= S of W never receive a factor: zero them once, so that the unused rows of D are zero
+  for (int e = tid; e < (32 - S) * RS; e += kBlock) T[(3 * S) * RS + e] = 0;
+
+  // staging role: lane = (token position x, one of NRG groups of actions); each trip handles 4 actions
+  constexpr int NRG = kBlock / G::A3;
+  constexpr int TB = 6;  // trips per batch: every byte load of a batch is in flight before one is used
+  const int sx = tid % G::A3, srg = tid / G::A3;
+  const int slo = sx < 2 * S ? -G::UVLIM : -128, shi = sx < 2 * S ? G::UVLIM : 127;
+
+  // tile role: this wavefront's column tiles are the same for every game
+  TileMap<S> tm;
+  make_tile_map<S>(tm, RS, wave, col, h);
+
+  // Token fetch and staging.  Buffer loads: one VGPR of lane offset + immediates instead of 24 64-bit addresses,
+  // and rows r >= R fall outside num_records (they read as 0), so no clamping.  fetch() only issues the loads of
+  // one batch (TB trips of 4 actions); commit() turns a batch into factors, checks their range and writes T.
+  auto fetch = [&](int64_t gg, int rb, int (&f)[TB][4]) {
+    const __amdgpu_buffer_rsrc_t tok = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int8_t*>(a.actions + gg * R * G::A3), 0, R * G::A3, 0x00027000);
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = rb + 4 * NRG * tb + t;
+        f[tb][t] = static_cast<int8_t>(__builtin_amdgcn_raw_buffer_load_b8(tok, sx + r * G::A3, 0, 0));
+      }
+  };
+  auto commit = [&](int rb, int (&f)[TB][4], int& big) {
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+      const int r0 = rb + 4 * NRG * tb;
+      if (r0 < Rp) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f[tb][t] = (r0 + t < R) ? f[tb][t] - a.shift : 0;
+          big |= (f[tb][t] < slo) | (f[tb][t] > shi);
+        }
+        *reinterpret_cast<uint32_t*>(T + sx * RS + r0) = pack4(f[tb][0], f[tb][1], f[tb][2], f[tb][3]);
+      }
+    }
+  };
+  // When one batch covers all the actions (R <= 4 NRG TB), the NEXT game's tokens are fetched right after this
+  // game's staging barrier and stay in registers through the tile phase: the memory latency (about a quarter of
+  // a game's time in this kernel) disappears behind the arithmetic.
+  const bool one_batch = Rp <= 4 * NRG * TB;  // uniform
+  int pf[TB][4];
+  if (one_batch && srg < NRG && static_cast<int64_t>(blockIdx.x) < a.B) fetch(blockIdx.x, 4 * srg, pf);
+
+  for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
+    // ---- 1. factors of this game, transposed into LDS (4 actions = one dword); range check; r >= R -> 0 ----
+    int big = 0;
+    if (srg < NRG) {
+      if (one_batch) {
+        commit(4 * srg, pf, big);
+      } else {
+        for (int rb = 4 * srg; rb < Rp; rb += 4 * NRG * TB) {
+          int f[TB][4];
+          fetch(g, rb, f);
+          commit(rb, f, big);
+        }
+      }
+    }
+    const bool too_big = __syncthreads_or(big);
+    if (one_batch && srg < NRG && g + gridDim.x < a.B) fetch(g + gridDim.x, 4 * srg, pf);
+    if (too_big) {  // workgroup-uniform; rare: exact byte-wise form
+      note_fallback();
+      slow_game<GENF>(a, g, flags);
+      __syncthreads();
+      continue;
+    }
+
+    // ---- 2. column tiles on the matrix cores, two at a time ----
+    int hi = 0, lo = 0;  // running max / min of every result of this lane
+    accumulate_tiles<S, KS>(T, img, Rp, tm, wave, col, h, hi, lo);
     const bool any_ovf = __syncthreads_or((hi > 127) | (lo < -128));  // also: the image is complete
 
     // ---- 3. image -> global, 16-byte chunks ----

@@ -257,10 +257,19 @@ STREAM_FACTORS = 0x00000000
 STREAM_BASIS = 0x80000000
 
 
+def thresholds16(thr):
+    """The generator draws 16-bit uniforms: a draw d16 selects values[#{t : d16 * 2^16 >= thr_t}], i.e. it is
+    compared with ceil(thr_t / 2^16) in [0, 65536] (the 32-bit cdf thresholds quantised upwards to 16 bits:
+    every probability is honoured to within 2^-16)."""
+    t = np.asarray(thr, np.uint64)
+    return ((t + np.uint64(0xFFFF)) >> np.uint64(16)).astype(np.uint32)
+
+
 def _draw_vector(seed: int, gid, sub: int, attempt, S: int, thr, values):
     """One attempt at one factor vector for every game in ``gid`` (uint64 array).
-    Counter = (gid_lo, gid_hi, sub, attempt<<8 | block); key = (seed_lo, seed_hi)."""
-    nblk = (S + 3) // 4
+    Counter = (gid_lo, gid_hi, sub, attempt<<8 | block); key = (seed_lo, seed_hi).  One Philox block yields EIGHT
+    16-bit draws: element e = 8*block + 2*m + half comes from output word m (x,y,z,w = 0..3), low half first."""
+    nblk = (S + 7) // 8
     B = gid.shape[0]
     ctr = np.zeros((B, nblk, 4), np.uint32)
     ctr[:, :, 0] = (gid & np.uint64(0xFFFFFFFF)).astype(np.uint32)[:, None]
@@ -268,8 +277,10 @@ def _draw_vector(seed: int, gid, sub: int, attempt, S: int, thr, values):
     ctr[:, :, 2] = np.uint32(sub)
     ctr[:, :, 3] = (np.asarray(attempt, np.uint32)[:, None] << np.uint32(8)) | np.arange(nblk, dtype=np.uint32)[None, :]
     key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], np.uint32)
-    d = philox4x32_10(ctr, np.broadcast_to(key, (B, nblk, 2))).reshape(B, nblk * 4)[:, :S]
-    idx = (d[:, :, None] >= np.asarray(thr, np.uint32)[None, None, :]).sum(axis=2)
+    w = philox4x32_10(ctr, np.broadcast_to(key, (B, nblk, 2)))            # (B, nblk, 4) words
+    d = np.stack([w & np.uint32(0xFFFF), w >> np.uint32(16)], axis=-1)     # (B, nblk, 4, 2): low half first
+    d = d.reshape(B, nblk * 8)[:, :S]
+    idx = (d[:, :, None] >= thresholds16(thr)[None, None, :]).sum(axis=2)
     return np.asarray(values, np.int64)[idx]
 
 

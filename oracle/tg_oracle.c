@@ -139,15 +139,18 @@ void tgo_gen_demos_i8(int8_t* target, int8_t* actions, uint8_t* overflow, int64_
         int8_t* dst = actions + ((b * R + r) * 3 + x) * S;
         for (uint32_t attempt = 0;; ++attempt) {
           int any = 0;
-          for (int q = 0; 4 * q < S; ++q) {
+          /* one Philox block = EIGHT 16-bit draws: element 8q + 2m + half from output word m, low half first;
+           * a draw d16 selects values[#{t : d16 * 2^16 >= thr_t}] (include/tensor_game.h) */
+          for (int q = 0; 8 * q < S; ++q) {
             uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)(3 * r + x), (attempt << 8) | (uint32_t)q};
             philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-            for (int t = 0; t < 4 && 4 * q + t < S; ++t) {
+            for (int t = 0; t < 8 && 8 * q + t < S; ++t) {
+              const uint64_t d = (uint64_t)((c[t >> 1] >> (16 * (t & 1))) & 0xFFFFu) << 16;
               int idx = 0;
-              for (int i = 0; i < nv - 1; ++i) idx += c[t] >= thr[i];
+              for (int i = 0; i < nv - 1; ++i) idx += d >= thr[i];
               const int f = values[idx];
               any |= f != 0;
-              dst[4 * q + t] = (int8_t)(f + shift);
+              dst[8 * q + t] = (int8_t)(f + shift);
             }
           }
           if (any || attempt + 1 >= (1u << 16)) break;

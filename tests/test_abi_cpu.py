@@ -27,7 +27,7 @@ def test_header_symbols_all_exported():
     lib = C.CDLL(str(_lib.LIB_PATH))
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.tg_abi_version() == 1
+    assert lib.tg_abi_version() == 2
     # the A/B variant exports the same entries plus the measurement-only one
     from mat_mul_amd import build
     extra = sorted(set(declared_symbols(ab=True)) - set(syms))

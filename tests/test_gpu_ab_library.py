@@ -101,7 +101,7 @@ def _run(script_text, tmp_path, marker, extra_env=None):
     assert res.returncode == 0 and marker in res.stdout, (res.stdout[-1000:], res.stderr[-3000:])
 
 
-@pytest.mark.parametrize("env_name", ["TG_FORCE_I32", "TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA", "TG_MFMA_MANY_ALWAYS"])
+@pytest.mark.parametrize("env_name", ["TG_FORCE_I32", "TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA", "TG_MFMA_MANY_ALWAYS", "TG_NO_FUSED_GEN"])
 def test_ab_switch_paths_stay_exact(env_name, tmp_path):
     """The measurement switches (32-bit cursor kernels; packed chunks instead of rows; vector ALU instead of
     the matrix cores) select kernels that the product dispatch no longer uses -- they must stay bit-exact."""

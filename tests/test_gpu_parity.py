@@ -42,7 +42,7 @@ def rand_case(rng, B, S, k=None, lo=-2, hi=3, terminal_every=5):
 @pytest.fixture(scope="module", autouse=True)
 def _native_loaded():
     assert torch.cuda.is_available(), "these tests need the MI355X"
-    assert mat_mul_amd._lib.lib.tg_abi_version() == 1
+    assert mat_mul_amd._lib.lib.tg_abi_version() == 2
     maps = open("/proc/self/maps").read()
     assert "libtensorgame.so" in maps, "the HIP library is not the one loaded"
 
