@@ -8,8 +8,10 @@ from pathlib import Path
 
 # TG_LIB_VARIANT=ab selects the A/B build (libtensorgame_ab.so, -DTG_AB_SWITCHES: the TG_* environment
 # switches, the first-generation kernels and tg_step_sparse_i8) -- measurement and A/B tests only.
-AB_VARIANT = os.environ.get("TG_LIB_VARIANT", "") == "ab"
-LIB_PATH = Path(__file__).resolve().parent / "lib" / ("libtensorgame_ab.so" if AB_VARIANT else "libtensorgame.so")
+_VARIANT = os.environ.get("TG_LIB_VARIANT", "")  # "", "ab", or "stamps" (ab + in-kernel time stamps; diagnostics only)
+AB_VARIANT = _VARIANT in ("ab", "stamps")
+LIB_PATH = Path(__file__).resolve().parent / "lib" / {"ab": "libtensorgame_ab.so", "stamps": "libtensorgame_stamps.so"}.get(
+    _VARIANT, "libtensorgame.so")
 
 TG_ABI_VERSION = 2
 TG_MAX_S = 32

@@ -25,6 +25,7 @@ LIB_DIR = PKG / "lib"
 OBJ_DIR = LIB_DIR / "obj"
 LIB_PATH = LIB_DIR / "libtensorgame.so"
 LIB_PATH_AB = LIB_DIR / "libtensorgame_ab.so"
+LIB_PATH_STAMPS = LIB_DIR / "libtensorgame_stamps.so"  # ab + in-kernel s_memtime stamps (tools/stamp_genfused.py); never shipped
 SOURCES = sorted(CSRC.glob("*.hip"))
 HEADERS = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "tensor_game.h"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
@@ -39,24 +40,24 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
-def lib_path(ab: bool = False) -> Path:
-    return LIB_PATH_AB if ab else LIB_PATH
+def lib_path(ab=False) -> Path:
+    return LIB_PATH_STAMPS if ab == "stamps" else (LIB_PATH_AB if ab else LIB_PATH)
 
 
 def _newest_input() -> float:
     return max(p.stat().st_mtime for p in SOURCES + HEADERS + [Path(__file__)])
 
 
-def is_stale(ab: bool = False) -> bool:
+def is_stale(ab=False) -> bool:
     lib = lib_path(ab)
     return (not lib.exists()) or lib.stat().st_mtime < _newest_input()
 
 
-def _obj(src: Path, ab: bool) -> Path:
-    return OBJ_DIR / f"{src.stem}{'.ab' if ab else ''}.o"
+def _obj(src: Path, ab) -> Path:
+    return OBJ_DIR / f"{src.stem}{'.stamps' if ab == 'stamps' else '.ab' if ab else ''}.o"
 
 
-def build(force: bool = False, verbose: bool = False, ab: bool = False) -> Path:
+def build(force: bool = False, verbose: bool = False, ab=False) -> Path:
     """Compile every HIP source (gfx950 only) and link the chosen variant of the library."""
     lib = lib_path(ab)
     if not force and not is_stale(ab):
@@ -64,7 +65,7 @@ def build(force: bool = False, verbose: bool = False, ab: bool = False) -> Path:
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
     hipcc = _hipcc()
     hdr_time = max(p.stat().st_mtime for p in HEADERS + [Path(__file__)])
-    extra = ["-DTG_AB_SWITCHES"] if ab else []
+    extra = ["-DTG_AB_SWITCHES", "-DTG_STAMPS"] if ab == "stamps" else (["-DTG_AB_SWITCHES"] if ab else [])
 
     def compile_one(src: Path):
         obj = _obj(src, ab)
@@ -98,4 +99,5 @@ def build(force: bool = False, verbose: bool = False, ab: bool = False) -> Path:
 if __name__ == "__main__":
     import sys
 
-    print(build(force="--force" in sys.argv, verbose=True, ab="--ab" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True,
+                ab="stamps" if "--stamps" in sys.argv else "--ab" in sys.argv))

@@ -129,18 +129,48 @@ __device__ __forceinline__ int draw_value16(uint32_t d16, const Dist& D) {
   return v;
 }
 
-// two 16-bit draws (the halves of one Philox output word) -> two int16 values, 3 packed ops per threshold
-__device__ __forceinline__ uint32_t draw_pair16(uint32_t w, const Dist& D) {
-  uint32_t v = D.base16;
-  if (D.nthr == 2) {  // wave-uniform: the ternary vocabulary
-    v = pk_mad_u16(pk_min_u16(pk_sub_u16_sat(w, D.c16[0]), 0x00010001u), D.delta16[0], v);
-    v = pk_mad_u16(pk_min_u16(pk_sub_u16_sat(w, D.c16[1]), 0x00010001u), D.delta16[1], v);
-    return v;
+// Packed evaluation of the draws of one Philox block: each output word holds two 16-bit draws; per threshold
+// m = min(max(d - (thr16 - 1), 0), 1) = [d >= thr16] and value += m * delta: three packed ops for two draws.  The
+// distribution's constants are wave-uniform and enter as SGPR operands (one per VOP3P instruction); `one` = 0x00010001
+// and `base` = D.base16 live in VGPRs of the caller.
+__device__ __forceinline__ uint32_t draw_step16(uint32_t w, uint32_t c16, uint32_t delta16, uint32_t one, uint32_t v) {
+  uint32_t m;
+  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(m) : "v"(w), "s"(c16));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(one));
+  asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(v) : "v"(m), "s"(delta16), "v"(v));
+  return v;
+}
+
+// eight draws (one Philox block) -> four dwords of two int16 values each: P[m] = values of elements 2m, 2m+1
+__device__ __forceinline__ void draw_block16(const uint32_t (&w)[4], const Dist& D, uint32_t one, uint32_t base,
+                                             uint32_t (&P)[4]) {
+  if (D.nthr == 2) {  // wave-uniform: the ternary vocabulary of the reference.  ONE asm statement: the four words are
+    // interleaved (independent chains) and no compiler padding separates the dependent packed ops
+    uint32_t t0, t1, t2, t3;
+    asm("v_pk_sub_u16 %4, %8, %12 clamp\n\tv_pk_sub_u16 %5, %9, %12 clamp\n\t"
+        "v_pk_sub_u16 %6, %10, %12 clamp\n\tv_pk_sub_u16 %7, %11, %12 clamp\n\t"
+        "v_pk_min_u16 %4, %4, %16\n\tv_pk_min_u16 %5, %5, %16\n\tv_pk_min_u16 %6, %6, %16\n\tv_pk_min_u16 %7, %7, %16\n\t"
+        "v_pk_mad_u16 %0, %4, %14, %17\n\tv_pk_mad_u16 %1, %5, %14, %17\n\t"
+        "v_pk_mad_u16 %2, %6, %14, %17\n\tv_pk_mad_u16 %3, %7, %14, %17\n\t"
+        "v_pk_sub_u16 %4, %8, %13 clamp\n\tv_pk_sub_u16 %5, %9, %13 clamp\n\t"
+        "v_pk_sub_u16 %6, %10, %13 clamp\n\tv_pk_sub_u16 %7, %11, %13 clamp\n\t"
+        "v_pk_min_u16 %4, %4, %16\n\tv_pk_min_u16 %5, %5, %16\n\tv_pk_min_u16 %6, %6, %16\n\tv_pk_min_u16 %7, %7, %16\n\t"
+        "v_pk_mad_u16 %0, %4, %15, %0\n\tv_pk_mad_u16 %1, %5, %15, %1\n\t"
+        "v_pk_mad_u16 %2, %6, %15, %2\n\tv_pk_mad_u16 %3, %7, %15, %3"
+        : "=&v"(P[0]), "=&v"(P[1]), "=&v"(P[2]), "=&v"(P[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "s"(D.c16[0]), "s"(D.c16[1]), "s"(D.delta16[0]), "s"(D.delta16[1]),
+          "v"(one), "v"(base));
+    return;
   }
 #pragma unroll
-  for (int t = 0; t < TG_MAX_VALUES - 1; ++t)
-    if (t < D.nthr) v = pk_mad_u16(pk_min_u16(pk_sub_u16_sat(w, D.c16[t]), 0x00010001u), D.delta16[t], v);
-  return v;
+  for (int m = 0; m < 4; ++m) P[m] = base;
+#pragma unroll
+  for (int t = 0; t < TG_MAX_VALUES - 1; ++t) {
+    if (t < D.nthr) {  // wave-uniform
+#pragma unroll
+      for (int m = 0; m < 4; ++m) P[m] = draw_step16(w[m], D.c16[t], D.delta16[t], one, P[m]);
+    }
+  }
 }
 
 // ---- Philox-4x32-10 (Salmon et al. SC'11); bit-identical to oracle/tensor_game.py -----------

@@ -12,7 +12,7 @@
 // mapping -- lane (col, h) owns elements k = 16h .. 16h+15 of the vector of action r0 + col -- so the change of basis
 // D[a][r] = sum_i M_x[a][i] f_r[i] takes the drawn bytes as they stand (A fragment = row `col` of M_x, read from
 // global memory), and without a basis the same registers go straight to T and to the token image.  One Philox block
-// is eight 16-bit draws evaluated two at a time with packed int16 ops (draw_pair16); a lane runs the blocks of its
+// is eight 16-bit draws evaluated two at a time with packed int16 ops (draw_block16); a lane runs the blocks of its
 // half (S = 25: blocks 2h, 2h+1; S <= 16: block h, handed to the lower half by v_permlane32_swap).  A vector that
 // comes out all zero is redrawn (attempt + 1) by its two lanes; the wavefront loops while any vector needs it
 // (P = 0.7^S per vector: 1.3e-4 at S = 25).
@@ -30,11 +30,35 @@ struct GenArgs {
   int R;
   int shift;
   Dist D;
+#ifdef TG_AB_SWITCHES
+  int ablate;  // A/B build only (TG_GF_ABLATE): 1 no Philox, 2 no LDS writes of the draw, 4 no tiles, 8 no target store, 16 no token store
+#endif
 };
+
+#ifdef TG_AB_SWITCHES
+#define TG_GF_ON(bit) (!(ga.ablate & (bit)))
+#else
+#define TG_GF_ON(bit) true
+#endif
+// Diagnostic build only (-DTG_STAMPS, tools/stamp_genfused.py): workgroups 0..19 record the shader clock at phase
+// boundaries into the OVERFLOW buffer (24 uint64 per workgroup; B >= 4096), which that build therefore does not use
+// as flags.  Never part of the product or of the A/B library.
+#ifdef TG_STAMPS
+#define TG_STAMP(i)                                                                                             \
+  do {                                                                                                          \
+    const int tg_stamp_i = (i);                                                                                 \
+    if (blockIdx.x < 20 && threadIdx.x == 0 && tg_stamp_i < 24)                                                 \
+      reinterpret_cast<unsigned long long*>(ga.overflow)[blockIdx.x * 24 + tg_stamp_i] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define TG_STAMP(i) \
+  do {              \
+  } while (0)
+#endif
 
 template <int S>
 constexpr int genfused_lds_bytes(int Rp, int R) {
-  return MGeo<S>::TROWS * (Rp + 16) + MGeo<S>::IMG + 32 + ((R * 3 * S + 15) & ~15) + 16 + 32;
+  return MGeo<S>::TROWS * (Rp + 16) + MGeo<S>::IMG + 32 + 2 * (((R * 3 * S + 15) & ~15) + 16) + 16;
 }
 
 // bytes 16h .. 16h+15 of an S-byte row in global memory (any alignment; nothing past the row is read; bytes >= S are 0)
@@ -59,11 +83,11 @@ __device__ __forceinline__ v4i row_fragment16(const int8_t* row, int h) {
 
 // The exact form of one game from its EMITTED tokens in LDS (any factor magnitude): the fallback of gen_fused_kernel
 // for games whose transformed factors leave the byte-product range of the matrix-core path.  Whole workgroup.
-template <int S>
+template <int S, int NTHREADS>
 __device__ __forceinline__ int exact_target_from_tokens(const uint8_t* tok, int R, int shift, int8_t* out) {
   constexpr int S2 = S * S, N = S2 * S, A3 = 3 * S;
   int ovf = 0;
-  for (int e = threadIdx.x; e < N; e += kBlock) {
+  for (int e = threadIdx.x; e < N; e += NTHREADS) {
     const int i = e / S2, rr = e - i * S2, j = rr / S, l = rr - j * S;
     int acc = 0;
     for (int r = 0; r < R; ++r) {
@@ -77,25 +101,40 @@ __device__ __forceinline__ int exact_target_from_tokens(const uint8_t* tok, int 
 }
 
 // KS: k-steps of 32 actions known at compile time (1 or 2: R <= 64), 0 = run-time Rp / 32.
-template <int S, int KS, bool BASIS>
-__global__ __launch_bounds__(kBlock) void gen_fused_kernel(GenArgs ga, int Rp) {
+//
+// Pipeline of one workgroup over its games g0, g1, ... (two barriers per game):
+//     draw(g0) | B1 | tiles(g0) | B2 | stores(g0) + draw(g1) | B1 | tiles(g1) | B2 | stores(g1) + draw(g2) | ...
+// The stores of a game (LDS images -> global memory, fire and forget) are issued by the wavefronts that have the
+// fewest draw jobs of the next game (3 Rp/32 jobs over 4 wavefronts: at R = 64 two wavefronts draw twice, the other two
+// draw once and store), so the memory phase hides behind the next game's Philox arithmetic.  The token image is double
+// buffered (draw(g+1) writes while stores(g) read); the target image and T are free again at B1 / B2 respectively.
+//
+// NW wavefronts per workgroup: 4, or 6 when the 3 Rp/32 draw jobs divide by 6 (R = 64: one job per wavefront instead of
+// two wavefronts drawing twice while two wait, and 20 tiles as 4+4+3+3+3+3 instead of 5 each).
+template <int S, int KS, bool BASIS, int NW>
+__global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) {
   using G = MGeo<S>;
+  constexpr int NTHREADS = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) uint8_t mfma_smem[];
   if constexpr (KS != 0) Rp = 32 * KS;
   const int RS = Rp + 16;
   const int R = ga.R, blk = R * G::A3;
+  const int tokbuf_bytes = ((blk + 15) & ~15) + 16;  // [pad + blk] bytes; pad = the block's 16-byte phase in global memory
   int8_t* const T = reinterpret_cast<int8_t*>(mfma_smem);
   uint8_t* const img = mfma_smem + G::TROWS * RS;
-  uint8_t* const tokimg = img + G::IMG + 32;  // [pad + blk] bytes; pad = the block's 16-byte phase in global memory
+  uint8_t* const tokimg = img + G::IMG + 32;  // two buffers of tokbuf_bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
+  if (static_cast<int64_t>(blockIdx.x) >= ga.B) return;
+  TG_STAMP(0);
+  if (!TG_GF_ON(32)) return;  // (A/B build: launch + dispatch only)
 
   // T starts all zero and only cells (x, i < S, r < R) are ever written: W rows l >= S and the padding actions
   // r >= R (up to Rp) stay zero for every game
-  for (int e = 16 * tid; e < G::TROWS * RS; e += 16 * kBlock) *reinterpret_cast<uint4*>(T + e) = uint4{0, 0, 0, 0};
+  for (int e = 16 * tid; e < G::TROWS * RS; e += 16 * NTHREADS) *reinterpret_cast<uint4*>(T + e) = uint4{0, 0, 0, 0};
 
-  TileMap<S> tm;
-  make_tile_map<S>(tm, RS, wave, col, h);
+  TileMap<S, NW> tm;
+  make_tile_map(tm, RS, wave, col, h);
 
   // draw role.  NB Philox blocks of 8 draws per vector.  NB <= 2: lane half h runs block h and the lower half
   // assembles the vector (elements 0..15); NB >= 3: lane half h runs blocks 2h, 2h+1 = its own 16 elements.
@@ -113,18 +152,21 @@ __global__ __launch_bounds__(kBlock) void gen_fused_kernel(GenArgs ga, int Rp) {
   const bool holds = kSwap ? (h == 0) : true;           // does this lane hold a fragment after assembly
   const uint32_t k0 = static_cast<uint32_t>(ga.seed), k1 = static_cast<uint32_t>(ga.seed >> 32);
   const uint32_t shp = (static_cast<uint32_t>(ga.shift) & 0xFFFFu) | (static_cast<uint32_t>(ga.shift) << 16);
+  uint32_t one16 = 0x00010001u, base16 = ga.D.base16;  // VGPR-resident operands of the packed draw evaluation
+  asm volatile("" : "+v"(one16), "+v"(base16));
   const int NTR = Rp >> 5, njob = 3 * NTR;
-  __syncthreads();
+  // store role: the wavefronts with the fewest draw jobs (wave >= njob % NW when the jobs do not divide evenly)
+  const int nheavy = njob % NW;                         // wavefronts 0 .. nheavy-1 draw once more than the others
+  const bool light = wave >= nheavy;
+  const int light_tid = tid - 64 * nheavy, light_threads = NTHREADS - 64 * nheavy;
 
-  for (int64_t g = blockIdx.x; g < ga.B; g += gridDim.x) {
+  auto token_pad = [&](int64_t g) { return static_cast<int>(reinterpret_cast<uintptr_t>(ga.actions + g * blk) & 15); };
+
+  // ---- draw (and transform) the factors of game g: registers -> T and the token image `tk` ----
+  auto draw = [&](int64_t g, uint8_t* tk, int& big, int& bad) {
+    if (!TG_GF_ON(64)) return;  // (A/B build: no draw phase at all)
     const uint64_t gid = ga.gid0 + static_cast<uint64_t>(g);
-    int8_t* const gtok = ga.actions + g * blk;
-    const int pad = static_cast<int>(reinterpret_cast<uintptr_t>(gtok) & 15);
-    uint8_t* const tk = tokimg + pad;
-    int bad = 0, big = 0;  // bad: a token left int8 (flag); big: factors beyond the byte products (exact fallback)
-
-    // ---- 1. draw (and transform) the factors: registers -> T and token image ----
-    for (int job = wave; job < njob; job += kBlock / 64) {
+    for (int job = wave; job < njob; job += NW) {
       const int x = job / NTR, r = 32 * (job - x * NTR) + col;
       const bool active = r < R;
       v4i fa;
@@ -135,20 +177,25 @@ __global__ __launch_bounds__(kBlock) void gen_fused_kernel(GenArgs ga, int Rp) {
       bool need = active && draws;
       uint32_t attempt = 0;
       while (true) {
-        if (need) {
+        if (need && !TG_GF_ON(1)) {
+          Dw[0] = 0x01FF0001u & vmask[0];
+          Kw[0] = 0x02000102u;
+        }
+        if (need && TG_GF_ON(1)) {
 #pragma unroll
           for (int b = 0; b < (kSwap ? 1 : 2); ++b) {
             if (8 * (q0 + b) < S) {
               const U4 o = philox4x32_10(U4{static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
                                             static_cast<uint32_t>(3 * r + x), (attempt << 8) | static_cast<uint32_t>(q0 + b)},
                                          k0, k1);
-              const uint32_t P0 = draw_pair16(o.x, ga.D), P1 = draw_pair16(o.y, ga.D);
-              const uint32_t P2 = draw_pair16(o.z, ga.D), P3 = draw_pair16(o.w, ga.D);
-              Dw[2 * b] = __builtin_amdgcn_perm(P1, P0, 0x06040200u) & vmask[2 * b];
-              Dw[2 * b + 1] = __builtin_amdgcn_perm(P3, P2, 0x06040200u) & vmask[2 * b + 1];
+              const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+              uint32_t P[4];
+              draw_block16(ow, ga.D, one16, base16, P);
+              Dw[2 * b] = __builtin_amdgcn_perm(P[1], P[0], 0x06040200u) & vmask[2 * b];
+              Dw[2 * b + 1] = __builtin_amdgcn_perm(P[3], P[2], 0x06040200u) & vmask[2 * b + 1];
               if constexpr (!BASIS) {
-                Kw[2 * b] = __builtin_amdgcn_perm(pk_add_u16(P1, shp), pk_add_u16(P0, shp), 0x06040200u);
-                Kw[2 * b + 1] = __builtin_amdgcn_perm(pk_add_u16(P3, shp), pk_add_u16(P2, shp), 0x06040200u);
+                Kw[2 * b] = __builtin_amdgcn_perm(pk_add_u16(P[1], shp), pk_add_u16(P[0], shp), 0x06040200u);
+                Kw[2 * b + 1] = __builtin_amdgcn_perm(pk_add_u16(P[3], shp), pk_add_u16(P[2], shp), 0x06040200u);
               }
             }
           }
@@ -176,12 +223,20 @@ __global__ __launch_bounds__(kBlock) void gen_fused_kernel(GenArgs ga, int Rp) {
         K = v4i{static_cast<int>(Kw[0]), static_cast<int>(Kw[1]), static_cast<int>(Kw[2]), static_cast<int>(Kw[3])};
       }
       if constexpr (!BASIS) {
-        if (active && holds) {
+        // elements k < KBOTH are valid in both lane halves (kbase 0 and 16), KBOTH <= k < KLOW only for kbase == 0:
+        // two straight runs of byte writes instead of sixteen individually predicated ones
+        constexpr int KBOTH = kSwap ? 0 : (S - 16 < 16 ? S - 16 : 16), KLOW = S < 16 ? S : 16;
+        if (active && holds && TG_GF_ON(2)) {
           int8_t* const tcol = T + (x * S + kbase) * RS + r;
           uint8_t* const trow = tk + (3 * r + x) * S + kbase;
 #pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            if (k < S && kbase + k < S) {
+          for (int k = 0; k < KBOTH; ++k) {
+            tcol[k * RS] = static_cast<int8_t>(static_cast<uint32_t>(F[k >> 2]) >> (8 * (k & 3)));
+            trow[k] = static_cast<uint8_t>(static_cast<uint32_t>(K[k >> 2]) >> (8 * (k & 3)));
+          }
+          if (kbase == 0) {
+#pragma unroll
+            for (int k = KBOTH; k < KLOW; ++k) {
               tcol[k * RS] = static_cast<int8_t>(static_cast<uint32_t>(F[k >> 2]) >> (8 * (k & 3)));
               trow[k] = static_cast<uint8_t>(static_cast<uint32_t>(K[k >> 2]) >> (8 * (k & 3)));
             }
@@ -193,53 +248,132 @@ __global__ __launch_bounds__(kBlock) void gen_fused_kernel(GenArgs ga, int Rp) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = 0;
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, F, acc, 0, 0, 0);
-        if (active) {
-          int8_t* const tcol = T + (x * S) * RS + r;
-          uint8_t* const trow = tk + (3 * r + x) * S;
-          const int lim = x < 2 ? G::UVLIM : 127;
+        if (active && TG_GF_ON(2)) {
+          int8_t* const tcol = T + (x * S + 4 * h) * RS + r;
+          uint8_t* const trow = tk + (3 * r + x) * S + 4 * h;
+          const int lim = x < 2 ? G::UVLIM : 127, lim_lo = x < 2 ? -G::UVLIM : -128;
+          auto emit = [&](int t) {  // register t = row a0 + 4 h, a0 = (t & 3) + 8 (t >> 2)
+            const int a0 = (t & 3) + 8 * (t >> 2);
+            const int f = acc[t], tokv = f + ga.shift;
+            big |= (f > lim) | (f < lim_lo);
+            bad |= tokv + 128;
+            tcol[a0 * RS] = static_cast<int8_t>(f);
+            trow[a0] = static_cast<uint8_t>(tokv);
+          };
 #pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const int a = (t & 3) + 8 * (t >> 2) + 4 * h;
-            if ((t & 3) + 8 * (t >> 2) < S && a < S) {
-              const int f = acc[t], tokv = f + ga.shift;
-              big |= (f > lim) | (f < -lim - (x < 2 ? 0 : 1));
-              bad |= tokv + 128;
-              tcol[a * RS] = static_cast<int8_t>(f);
-              trow[a] = static_cast<uint8_t>(tokv);
-            }
+          for (int t = 0; t < 16; ++t)
+            if ((t & 3) + 8 * (t >> 2) + 4 < S) emit(t);  // valid in both lane halves
+          if (h == 0) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+              if ((t & 3) + 8 * (t >> 2) < S && (t & 3) + 8 * (t >> 2) + 4 >= S) emit(t);  // lower half only
           }
         }
       }
     }
-    const int verdict = __syncthreads_or((big ? 1 : 0) | ((bad & ~255) ? 2 : 0));  // also: T and the token image are complete
-    int8_t* const out = ga.target + g * ga.out_stride;
-    bool any_ovf = (verdict & 2) != 0;
-    if (verdict & 1) {  // workgroup-uniform; rare: exact byte-wise form from the emitted tokens
+  };
+
+  // ---- LDS images of game g -> global memory, by threads t = 0 .. nthr-1: target (unless the exact path already wrote
+  // it) as 16-byte chunks; tokens = the block's bytes [pad, pad + blk) of the image, aligned 16-byte chunks inside ----
+  // `n` whole 16-byte chunks LDS -> global by threads t = 0 .. nthr-1, four chunks per thread and trip: the four LDS reads
+  // are issued together, then the four stores (a read-wait-store chain per chunk made this phase, a few chunks per thread,
+  // cost ~2 us of latency per game).  Reads past the end are clamped, not predicated; named values, not an array (hipcc
+  // put a conditionally written uint4 array into scratch).
+  auto copy_chunks = [&](const uint8_t* src, uint8_t* dst, int n, int t, int nthr) {
+    for (int c0 = t; c0 < n; c0 += 4 * nthr) {
+      const int c1 = c0 + nthr, c2 = c1 + nthr, c3 = c2 + nthr;
+      const uint4 q0 = *reinterpret_cast<const uint4*>(src + 16 * c0);
+      const uint4 q1 = *reinterpret_cast<const uint4*>(src + 16 * (c1 < n ? c1 : n - 1));
+      const uint4 q2 = *reinterpret_cast<const uint4*>(src + 16 * (c2 < n ? c2 : n - 1));
+      const uint4 q3 = *reinterpret_cast<const uint4*>(src + 16 * (c3 < n ? c3 : n - 1));
+      *reinterpret_cast<uint4*>(dst + 16 * c0) = q0;
+      if (c1 < n) *reinterpret_cast<uint4*>(dst + 16 * c1) = q1;
+      if (c2 < n) *reinterpret_cast<uint4*>(dst + 16 * c2) = q2;
+      if (c3 < n) *reinterpret_cast<uint4*>(dst + 16 * c3) = q3;
+    }
+  };
+
+  // ---- LDS images of game g -> global memory, by threads t = 0 .. nthr-1: target (unless the exact path already wrote
+  // it) as 16-byte chunks; tokens = the block's bytes [pad, pad + blk) of the image, aligned 16-byte chunks inside ----
+  auto store_outputs = [&](int64_t g, const uint8_t* tbuf, bool with_target, int t, int nthr) {
+    if (with_target && TG_GF_ON(8)) {
+      int8_t* const out = ga.target + g * ga.out_stride;
+      constexpr int NFULL = G::TAIL ? G::NCHUNK - 1 : G::NCHUNK;  // whole 16-byte chunks
+      copy_chunks(img, reinterpret_cast<uint8_t*>(out), NFULL, t, nthr);
+      if (G::TAIL != 0 && t < G::TAIL) out[16 * NFULL + t] = static_cast<int8_t>(img[16 * NFULL + t]);
+    }
+    if (TG_GF_ON(16)) {
+      const int pad = token_pad(g);
+      uint8_t* const gbase = reinterpret_cast<uint8_t*>(ga.actions + g * blk) - pad;
+      const int total = pad + blk;
+      const int cfirst = (pad + 15) >> 4, cend = total >> 4;  // whole chunks [cfirst, cend) lie inside [pad, total)
+      if (cend > cfirst) copy_chunks(tbuf + 16 * cfirst, gbase + 16 * cfirst, cend - cfirst, t, nthr);
+      // the bytes in front of the first and behind the last whole chunk (none when the block is aligned)
+      const int head_end = 16 * cfirst < total ? 16 * cfirst : total;
+      if (pad + t < head_end) gbase[pad + t] = tbuf[pad + t];
+      const int tail0 = 16 * cend > head_end ? 16 * cend : head_end;
+      if (tail0 + t < total) gbase[tail0 + t] = tbuf[tail0 + t];
+    }
+  };
+
+  // Workgroup OR of a per-thread flag with ONE barrier (HIP's __syncthreads_or costs three): non-zero flags are OR-ed
+  // into an LDS word (rare), barrier, everyone reads the word.  Four words used round-robin; a word is cleared by
+  // thread 0 after the NEXT barrier (every reader has passed it by then) and needed again three barriers later.
+  uint32_t* const orw = reinterpret_cast<uint32_t*>(tokimg + 2 * tokbuf_bytes);
+  if (tid < 4) orw[tid] = 0;
+  int orslot = 0;
+  auto wg_or = [&](int v) {
+    if (v) atomicOr(&orw[orslot], static_cast<uint32_t>(v));
+    __syncthreads();
+    const int r = static_cast<int>(orw[orslot]);
+    if (tid == 0) orw[(orslot + 3) & 3] = 0;  // the word of the previous barrier
+    orslot = (orslot + 1) & 3;
+    return r;
+  };
+
+  __syncthreads();  // T and the OR words are zero
+  TG_STAMP(1);
+  int64_t prev = -1, cur = blockIdx.x;
+  bool prev_exact = false;
+  int buf = 0;
+  int stamp = 2;
+  (void)stamp;
+  while (true) {
+    const bool has_cur = cur < ga.B;
+    // stores of the previous game: by everybody when nothing follows, else by the wavefronts that draw least
+    if (prev >= 0) {
+      const uint8_t* const pbuf = tokimg + (buf ^ 1) * tokbuf_bytes;
+      if (!has_cur) store_outputs(prev, pbuf, !prev_exact, tid, NTHREADS);
+      else if (light) store_outputs(prev, pbuf, !prev_exact, light_tid, light_threads);
+    }
+    TG_STAMP(stamp++);  // stores of prev issued (thread 0 belongs to a drawing wavefront: ~ loop top)
+    if (!has_cur) break;
+    uint8_t* const tbuf = tokimg + buf * tokbuf_bytes;
+    int big = 0, bad = 0;  // big: factors beyond the byte products (exact fallback); bad: a token left int8 (flag)
+    draw(cur, tbuf + token_pad(cur), big, bad);
+    TG_STAMP(stamp++);  // own draw jobs done
+    const int verdict = wg_or((big ? 1 : 0) | ((bad & ~255) ? 2 : 0));  // B1: T, token image complete; image reads of prev done
+    TG_STAMP(stamp++);  // B1 passed
+    const bool exact = (verdict & 1) != 0;  // workgroup-uniform; rare
+    int flag = 0;
+    if (exact) {  // exact byte-wise form from the emitted tokens, straight to global memory
       note_fallback();
-      any_ovf |= __syncthreads_or(exact_target_from_tokens<S>(tk, R, ga.shift, out)) != 0;
-    } else {
-      // ---- 2. column tiles on the matrix cores ----
+      flag = exact_target_from_tokens<S, NTHREADS>(tbuf + token_pad(cur), R, ga.shift, ga.target + cur * ga.out_stride);
+    } else {  // column tiles on the matrix cores -> the target image
       int hi = 0, lo = 0;
-      accumulate_tiles<S, KS>(T, img, Rp, tm, wave, col, h, hi, lo);
-      any_ovf |= __syncthreads_or((hi > 127) | (lo < -128)) != 0;  // also: the image is complete
-      // ---- 3. image -> global, 16-byte chunks ----
-      for (int c = tid; c < G::NCHUNK; c += kBlock)
-        store_chunk<G::TAIL>(out + 16 * c, *reinterpret_cast<const uint4*>(img + 16 * c), c == G::NCHUNK - 1);
+      if (TG_GF_ON(4)) accumulate_tiles<S, KS, NW>(T, img, Rp, tm, wave, col, h, hi, lo);
+      flag = (hi > 127) | (lo < -128);
     }
-    // ---- 4. tokens -> global: the block's bytes [pad, pad + blk) of the image, aligned 16-byte chunks inside ----
-    {
-      uint8_t* const gbase = reinterpret_cast<uint8_t*>(gtok) - pad;
-      const int total = pad + blk, nchunk = (total + 15) >> 4;
-      for (int c = tid; c < nchunk; c += kBlock) {
-        const int b0 = 16 * c, b1 = b0 + 16;
-        if (b0 >= pad && b1 <= total) {
-          *reinterpret_cast<uint4*>(gbase + b0) = *reinterpret_cast<const uint4*>(tokimg + b0);
-        } else {
-          for (int b = b0 < pad ? pad : b0; b < (b1 < total ? b1 : total); ++b) gbase[b] = tokimg[b];
-        }
-      }
-    }
-    if (tid == 0 && any_ovf && ga.overflow) ga.overflow[g] = 1;
-    __syncthreads();  // T and the images are reused by the next game
+    TG_STAMP(stamp++);  // own tiles done
+    const bool any_ovf = (wg_or(flag) != 0) | ((verdict & 2) != 0);  // B2: the image is complete, T is free
+#ifndef TG_STAMPS
+    if (tid == 0 && any_ovf && ga.overflow) ga.overflow[cur] = 1;
+#else
+    (void)any_ovf;
+#endif
+    prev = cur;
+    prev_exact = exact;
+    cur += gridDim.x;
+    buf ^= 1;
   }
 }

@@ -74,17 +74,17 @@ struct __attribute__((packed)) UnalignedU32 { uint32_t v; };  // gfx950 LDS take
 
 // ---- the tile phase shared by genf_mfma_kernel and gen_fused_kernel (tg_genfused.h) -----------------------------
 // Which column tiles a wavefront owns, and where its lanes read their fragments: the same for every game.
-template <int S>
+template <int S, int NW_ = kBlock / 64>  // NW_ wavefronts share the NT column tiles of a game
 struct TileMap {
-  static constexpr int NW = kBlock / 64, TPW = (MGeo<S>::NT + NW - 1) / NW;
+  static constexpr int NW = NW_, TPW = (MGeo<S>::NT + NW - 1) / NW;
   int uoff[TPW], voff[TPW], ncol[TPW];
   int woff;
 };
 
-template <int S>
-__device__ __forceinline__ void make_tile_map(TileMap<S>& tm, int RS, int wave, int col, int h) {
+template <int S, int NW_>
+__device__ __forceinline__ void make_tile_map(TileMap<S, NW_>& tm, int RS, int wave, int col, int h) {
   using G = MGeo<S>;
-  constexpr int NW = TileMap<S>::NW, TPW = TileMap<S>::TPW;
+  constexpr int NW = NW_, TPW = TileMap<S, NW_>::TPW;
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
     const int n = 32 * (wave + NW * k) + col;
@@ -99,11 +99,11 @@ __device__ __forceinline__ void make_tile_map(TileMap<S>& tm, int RS, int wave, 
 
 // All column tiles of one game: T (transposed factors, rows of RS = Rp + 16 bytes) -> the dense S^3 byte image `img`.
 // hi / lo: running max / min of every int32 result of this lane (the int8 range check).
-template <int S, int KS>
-__device__ __forceinline__ void accumulate_tiles(const int8_t* T, uint8_t* img, int Rp, const TileMap<S>& tm, int wave,
+template <int S, int KS, int NW_>
+__device__ __forceinline__ void accumulate_tiles(const int8_t* T, uint8_t* img, int Rp, const TileMap<S, NW_>& tm, int wave,
                                                  int col, int h, int& hi, int& lo) {
   using G = MGeo<S>;
-  constexpr int NW = TileMap<S>::NW, TPW = TileMap<S>::TPW;
+  constexpr int NW = NW_, TPW = TileMap<S, NW_>::TPW;
   const int (&uoff)[TPW] = tm.uoff;
   const int (&voff)[TPW] = tm.voff;
   const int (&ncol)[TPW] = tm.ncol;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) 
 
   // tile role: this wavefront's column tiles are the same for every game
   TileMap<S> tm;
-  make_tile_map<S>(tm, RS, wave, col, h);
+  make_tile_map(tm, RS, wave, col, h);
 
   // Token fetch and staging.  Buffer loads: one VGPR of lane offset + immediates instead of 24 64-bit addresses,
   // and rows r >= R fall outside num_records (they read as 0), so no clamping.  fetch() only issues the loads of
