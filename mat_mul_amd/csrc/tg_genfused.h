@@ -111,7 +111,9 @@ __device__ __forceinline__ int exact_target_from_tokens(const uint8_t* tok, int 
 //
 // NW wavefronts per workgroup: 4, or 6 when the 3 Rp/32 draw jobs divide by 6 (R = 64: one job per wavefront instead of
 // two wavefronts drawing twice while two wait, and 20 tiles as 4+4+3+3+3+3 instead of 5 each).
-template <int S, int KS, bool BASIS, int NW>
+// CHECK = false (host-proved, BASIS = false only): R * max|value|^3 <= 127, so no target entry can leave int8 and the
+// tiles skip their range tracking (the reference's {-1,0,1} with R <= 127).
+template <int S, int KS, bool BASIS, int NW, bool CHECK = true>
 __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) {
   using G = MGeo<S>;
   constexpr int NTHREADS = 64 * NW;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
       flag = exact_target_from_tokens<S, NTHREADS>(tbuf + token_pad(cur), R, ga.shift, ga.target + cur * ga.out_stride);
     } else {  // column tiles on the matrix cores -> the target image
       int hi = 0, lo = 0;
-      if (TG_GF_ON(4)) accumulate_tiles<S, KS, NW>(T, img, Rp, tm, wave, col, h, hi, lo);
+      if (TG_GF_ON(4)) accumulate_tiles<S, KS, NW, CHECK>(T, img, Rp, tm, wave, col, h, hi, lo);
       flag = (hi > 127) | (lo < -128);
     }
     TG_STAMP(stamp++);  // own tiles done

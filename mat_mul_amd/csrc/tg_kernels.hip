@@ -1224,55 +1224,38 @@ int tg_internal_gen_fused(int8_t* target, int8_t* actions, uint8_t* overflow, co
   ga.ablate = getenv("TG_GF_ABLATE") ? atoi(getenv("TG_GF_ABLATE")) : 0;
   wgs_override = getenv("TG_GF_WGS") ? atoi(getenv("TG_GF_WGS")) : 0;
 #endif
-#define TG_GF_K(S_, KS_, BAS_, NW_)                                                                \
+#define TG_GF_K(S_, KS_, BAS_, CHK_)                                                               \
   do {                                                                                             \
     const int ldsb = genfused_lds_bytes<S_>(Rp, R);                                                \
     static OccupancySlots occ;                                                                     \
-    int per_cu = 0;                                                                                \
-    if (wgs_override > 0) {                                                                        \
-      per_cu = wgs_override;                                                                       \
-    } else {                                                                                       \
-      const uint64_t tag = (static_cast<uint64_t>(ldsb) + 1) << 32;                                \
-      const int dev = current_device();                                                            \
-      const uint64_t c = dev >= 0 ? occ.v[dev].load(std::memory_order_relaxed) : 0;                \
-      if ((c & ~0xffffffffull) == tag) {                                                           \
-        per_cu = static_cast<int>(c & 0xffffffffull);                                              \
-      } else {                                                                                     \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gen_fused_kernel<S_, KS_, BAS_, NW_>, 64 * NW_, ldsb) != hipSuccess || per_cu < 1) per_cu = 1; \
-        (void)hipGetLastError();                                                                   \
-        if (dev >= 0) occ.v[dev].store(tag | static_cast<uint32_t>(per_cu), std::memory_order_relaxed); \
-      }                                                                                            \
-    }                                                                                              \
+    const int per_cu = wgs_override > 0 ? wgs_override : resident_per_cu(gen_fused_kernel<S_, KS_, BAS_, 4, CHK_>, ldsb, occ); \
     /* twice as many workgroups as fit at once (two games each at B = 4096): the second wave of workgroups fills */ \
     /* the chip as the first ones finish, which evens out the tail (measured: 40 -> 38 us) */     \
     const int64_t resident = static_cast<int64_t>(per_cu) * device_cu_count() * (wgs_override > 0 ? 1 : 2); \
     const int64_t per_wg = (B + resident - 1) / resident;                                          \
     const int64_t grid = (B + per_wg - 1) / per_wg;                                                \
     (void)hipGetLastError();                                                                       \
-    hipLaunchKernelGGL((gen_fused_kernel<S_, KS_, BAS_, NW_>), dim3((unsigned)grid), dim3(64 * NW_), ldsb, st, ga, Rp); \
+    hipLaunchKernelGGL((gen_fused_kernel<S_, KS_, BAS_, 4, CHK_>), dim3((unsigned)grid), dim3(kBlock), ldsb, st, ga, Rp); \
     if (int rc = check_launch(fn)) return rc;                                                      \
     return 1;                                                                                      \
   } while (0)
-#define TG_GF_B(S_, BAS_)                                                                          \
+#define TG_GF_B(S_, BAS_, CHK_)                                                                    \
   do {                                                                                             \
-    if (Rp == 32) TG_GF_K(S_, 1, BAS_, 4);                                                         \
-    if (Rp == 64 && nw == 3) TG_GF_K(S_, 2, BAS_, 3);                                              \
-    if (Rp == 64 && nw == 6) TG_GF_K(S_, 2, BAS_, 6);                                              \
-    if (Rp == 64) TG_GF_K(S_, 2, BAS_, 4);                                                         \
-    if (nw == 3) TG_GF_K(S_, 0, BAS_, 3);                                                          \
-    TG_GF_K(S_, 0, BAS_, 4);                                                                       \
+    if (Rp == 32) TG_GF_K(S_, 1, BAS_, CHK_);                                                      \
+    if (Rp == 64) TG_GF_K(S_, 2, BAS_, CHK_);                                                      \
+    TG_GF_K(S_, 0, BAS_, CHK_);                                                                    \
   } while (0)
 #define TG_GF(S_)                                                                                  \
   do {                                                                                             \
-    if (basis) TG_GF_B(S_, true);                                                                  \
-    TG_GF_B(S_, false);                                                                            \
+    if (basis) TG_GF_B(S_, true, true);                                                            \
+    if (!in_range) TG_GF_B(S_, false, true);                                                       \
+    TG_GF_B(S_, false, false);                                                                     \
   } while (0)
-  // wavefronts per workgroup: three when the 3 Rp/32 draw jobs divide by three but not by four (R = 64: two jobs per
-  // wavefront instead of two wavefronts drawing twice while two wait) and the game has tiles enough for them
-  int nw = 4;  // (three wavefronts, two jobs each at R = 64, measured slower: the kernel is bound by VALU issue, not balance)
-#ifdef TG_AB_SWITCHES
-  if (getenv("TG_GF_NW")) nw = atoi(getenv("TG_GF_NW"));
-#endif
+  // without a basis the factors are the drawn values: when R * max|value|^3 <= 127 no entry of a target can leave
+  // int8 (the reference's {-1,0,1} up to R = 127) and the tiles need no range tracking
+  int fmax = 0;
+  for (int t = 0; t < D.nv; ++t) fmax = D.val[t] > fmax ? D.val[t] : (-D.val[t] > fmax ? -D.val[t] : fmax);
+  const bool in_range = !basis && static_cast<int64_t>(R) * fmax * fmax * fmax <= 127 && !TG_SWITCH("TG_GF_ALWAYS_CHECK");
   if (S == 9) TG_GF(9);
   if (S == 16) TG_GF(16);
   TG_GF(25);

@@ -99,7 +99,9 @@ __device__ __forceinline__ void make_tile_map(TileMap<S, NW_>& tm, int RS, int w
 
 // All column tiles of one game: T (transposed factors, rows of RS = Rp + 16 bytes) -> the dense S^3 byte image `img`.
 // hi / lo: running max / min of every int32 result of this lane (the int8 range check).
-template <int S, int KS, int NW_>
+// CHECK = false: the caller has proved that no result can leave int8 (R * fmax^3 <= 127): the running max / min
+// (sixteen VALU instructions per tile) is dropped and hi / lo stay untouched.
+template <int S, int KS, int NW_, bool CHECK = true>
 __device__ __forceinline__ void accumulate_tiles(const int8_t* T, uint8_t* img, int Rp, const TileMap<S, NW_>& tm, int wave,
                                                  int col, int h, int& hi, int& lo) {
   using G = MGeo<S>;
@@ -132,10 +134,12 @@ __device__ __forceinline__ void accumulate_tiles(const int8_t* T, uint8_t* img, 
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, p, acc, 0, 0, 0);
         }
       }
+      if constexpr (CHECK) {
 #pragma unroll
-      for (int t2 = 0; t2 < 16; t2 += 2) {
-        hi = max(max(acc[t2], acc[t2 + 1]), hi);
-        lo = min(min(acc[t2], acc[t2 + 1]), lo);
+        for (int t2 = 0; t2 < 16; t2 += 2) {
+          hi = max(max(acc[t2], acc[t2 + 1]), hi);
+          lo = min(min(acc[t2], acc[t2 + 1]), lo);
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) X[q] = pack4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);

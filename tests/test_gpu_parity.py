@@ -415,6 +415,26 @@ def test_generator_bit_exact(S, B, R):
     assert np.array_equal(host(g_tok), w_tok) and np.array_equal(host(g_tgt), w_tgt)
 
 
+@pytest.mark.parametrize("S,B,R,values,probs", [
+    (9, 21, 200, (-2, -1, 0, 1, 2), (3, 2, 1, 2, 3)),      # dense +-2 factors, long lists: targets overflow (range-checked tiles)
+    (16, 9, 130, (-1, 0, 1), (0.15, 0.7, 0.15)),           # ternary but R > 127: the bound R * f^3 <= 127 fails
+    (25, 6, 127, (-1, 0, 1), (0.3, 0.4, 0.3)),             # ternary, R = 127: the unchecked tiles, at their limit
+    (25, 5, 256, (-1, 0, 1), (0.15, 0.7, 0.15)),           # the largest R of the fused kernel
+    (16, 7, 33, (0, 3), (0.5, 0.5)),                        # two categories (one threshold), tokens 1 and 4
+    (9, 30, 8, (-11, 0, 11), (0.2, 0.6, 0.2)),              # factors at the byte-product limit of the matrix-core path
+    (9, 30, 8, (-12, 0, 12), (0.2, 0.6, 0.2)),              # one beyond it: token kernel + tg_gen_from_factors_i8
+])
+def test_generator_overflow_flags_and_vocabularies(S, B, R, values, probs):
+    """tg_gen_demos_i8 against the oracle where the fused kernel switches variants: range-checked and unchecked tiles,
+    run-time k-loop, general (non-ternary) draw evaluation, and the fall-back to the two-kernel path."""
+    thr = O.categorical_thresholds(probs)
+    want_tok, want_tgt, want_ovf = O.gen_demos_i8(B, S, R, thr, values, 1, seed=77, game_id_offset=5)
+    ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    tok, tgt = ops.gen_demos(B, S, R, DEV, values=values, probs=probs, seed=77, game_id_offset=5, overflow=ovf)
+    assert np.array_equal(host(tok), want_tok) and np.array_equal(host(tgt), want_tgt)
+    assert np.array_equal(host(ovf), want_ovf)
+
+
 def test_generator_distribution_vs_reference(golden):
     from scipy import stats
     g = golden("sampler_stats")
