@@ -606,6 +606,43 @@ def also_lines(S_main, B_main, dev, mode):
                      "ok": bool(((ds >= 0) & (ds < k2)).all()) and not bool(st2.any()),
                      "value": round(b2 * k2 / sec, 1), "unit": "steps/s",
                      "us_per_launch": round(sec * 1e6, 2), "GBps": round(nbytes / sec / 1e9, 1)})
+    # the streamed stepper (its own entry and metric): K steps in ONE resident launch, the state stays in registers,
+    # per step poll + 12 token bytes in + state and done written through + a progress word per wavefront
+    for (b2, k2) in [(65536, 1008), (131072, 504)]:
+        s2, r2 = 4, 7
+        tok, tgt = ops.gen_demos(b2, s2, r2, dev, seed=4)
+        cyc = torch.cat([tok, tok], dim=1)
+        cyc[:, r2:, :s2] = 2 - cyc[:, r2:, :s2]                  # the same terms with u negated: period 14
+        acts = cyc.permute(1, 0, 2).contiguous().repeat(k2 // (2 * r2), 1, 1)   # (K, B, 12) step-major
+        st2 = ops.alloc_states(b2, s2, dev)
+        st2.copy_(tgt)
+        dn = torch.empty((k2, b2), dtype=torch.uint8, device=dev)
+        ready = torch.ones(k2, dtype=torch.int32, device=dev)    # pre-set: the producer is never the bottleneck
+        prog = torch.zeros(ops.step_stream_layout(b2, s2, dev)[0], dtype=torch.int32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        fn = lambda: ops.step_stream(st2, acts, done=dn, ready=ready, progress=prog, status=status)
+        fn()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        sec = statistics.median(ts)
+        ok = bool(torch.equal(st2, tgt)) and int(status[0]) == 0 and bool((prog == k2).all()) \
+            and bool(dn[r2 - 1].all()) and not bool(dn[0].all())
+        moved = b2 * (s2 ** 3 + 3 * s2 + 1)                       # per step: tokens in, state + done out (no state read)
+        also.append({"workload": f"STREAMED tg_step_stream_i8: S={s2} batch={b2}, K={k2} steps in ONE launch, actions "
+                                 f"consumed step by step (ready words pre-set), progress published per wavefront; "
+                                 f"not the single-step metric",
+                     "ok": ok, "value": round(b2 * k2 / sec, 1), "unit": "steps/s", "us_per_step": round(sec / k2 * 1e6, 3),
+                     "GBps_moved": round(moved * k2 / sec / 1e9, 1),
+                     "frac_of_hbm_peak_moved_bytes": round(moved * k2 / sec / 1e9 / HBM_PEAK_GBS, 4),
+                     "note": "bytes moved per step = S^3 + 3S + 1 per game (the state is not re-read: it lives in registers)"})
+        del acts, dn
     # BASELINE config 5's generator (per-GPU share: 4 096 demos, S=25, R=64), with and without the change
     # of basis; bytes = target + tokens written (S^3 + 3SR per demo); replayed as a hipGraph
     for with_basis in (False, True):

@@ -89,6 +89,28 @@ int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* act
                     int32_t* done_step, uint8_t* overflow, int64_t B, int S, int K,
                     int64_t game_stride_bytes, int shift, tg_stream_t stream);
 
+/* K in-place steps in ONE launch, for action blocks that become available step by step -- a device-side producer
+ * (the policy network choosing the next action from the state, act.py:182-183 / training.py:249-255) or a host
+ * thread writing through mapped memory.  Same results as K calls of tg_step_i8(state, state, actions[k], done[k], ...);
+ * what it removes is the dependent-launch boundary between two steps (1.55 us on MI355X, more than the step itself
+ * at S=4, B=65 536): the stepper stays resident, keeps every game's state in registers and per step only polls,
+ * reads 12 token bytes per game and writes the new state through.
+ *   actions: int8 (K,B,3S), STEP-major.  ready: uint32 (K) or NULL; step k reads its block once ready[k] != 0
+ *   (the producer writes the block, then ready[k], with release semantics at agent scope or wider); NULL = every
+ *   block is valid at launch.  done: uint8 (K,B), done[k][b] as tg_step_i8 would report after step k.
+ *   progress: uint32 (n_units) or NULL; the games are owned by n_units wavefronts, unit u = games
+ *   [u*games_per_unit, (u+1)*games_per_unit) (tg_step_stream_layout); once the state and done[k] of its games are
+ *   visible to other agents (write-through stores, drained) unit u stores k+1 into progress[u].
+ *   status: uint32 (1) or NULL, set to 1 if a wavefront gave up waiting for a ready word (bounded spin, ~1 s).
+ * No wavefront ever waits for another one, so the launch cannot deadlock on residency.  S = 4 only in this build
+ * (TG_ERR_UNSUPPORTED otherwise), states 16-byte aligned.  This is a separate entry with its own metric: the
+ * single-step figures of tg_step_i8 never include it. */
+int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8_t* overflow,
+                      const uint32_t* ready, uint32_t* progress, uint32_t* status, int64_t B, int S, int K,
+                      int64_t game_stride_bytes, int shift, tg_stream_t stream);
+/* n_units (wavefronts) and games_per_unit of tg_step_stream_i8 for B games (host call, no device work). */
+int tg_step_stream_layout(int64_t B, int S, int64_t* n_units, int* games_per_unit);
+
 /* k children per parent: state_out[b*k+i] = state_in[b] - tensor(actions[b][i]).
  * done, changed, overflow: uint8 (B,k); changed[b][i] = child differs from parent (the per-game
  * form of remove_null_actions, utils.py:191-194); changed/overflow may be NULL.

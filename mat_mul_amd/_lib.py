@@ -36,6 +36,8 @@ SIGNATURES = {
     "tg_debug_fallbacks": [_p],
     "tg_step_i8": [_p, _p, _p, _p, _p, _i64, _i, _i64, _i, _p],
     "tg_step_many_i8": [_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _p],
+    "tg_step_stream_i8": [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _p],
+    "tg_step_stream_layout": [_i64, _i, _p, _p],
     "tg_expand_i8": [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i, _p],
     "tg_copy_i8": [_p, _p, _i64, _i, _i64, _i64, _p],
     "tg_done_i8": [_p, _p, _p, _i64, _i, _i64, _p],

@@ -761,6 +761,94 @@ __global__ __launch_bounds__(kBlock) void s4_expand_kernel(ApplyArgs a, int PB, 
 }
 
 // =============================================================================================
+// tg_step_stream_i8, S = 4: K steps in ONE launch for action blocks that arrive step by step.
+// The dependent-launch boundary (1.55 us between two kernels of one stream) is what bounds the
+// single-step entry at BASELINE config 2; a stepper that stays resident pays instead its own chain per step:
+//   poll ready[k] (sc1 load) -> the 12 token bytes (sc1 loads: the producer is another kernel or the host) ->
+//   8 packed MADs per slice -> state + done stored write-through (sc1) -> drain -> progress word (sc1 store).
+// Games are independent, so there is NO barrier of any kind: the unit of work and of progress is the WAVEFRONT
+// (16 games x NG, four lanes per game, the slices stay in VGPRs for all K steps).  Unit u = global wavefront index
+// owns games [u * 16 NG, (u + 1) * 16 NG) and stores k + 1 into progress[u] once step k of its games is visible.
+// Every spin is bounded: a wavefront whose ready word never arrives sets *status = 1 and leaves.
+// =============================================================================================
+struct StreamArgs {
+  int8_t* state;
+  const int8_t* actions;    // (K, B, 12) step-major
+  uint8_t* done;            // (K, B)
+  uint8_t* overflow;        // (B), nullable, sticky
+  const uint32_t* ready;    // (K), nullable: all blocks valid at launch
+  uint32_t* progress;       // (units), nullable
+  uint32_t* status;         // (1), nullable
+  int64_t B;
+  int64_t stride;
+  int K;
+  int shift;
+  uint32_t spin_limit;
+};
+
+template <int NG>
+__global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
+  const int lane = threadIdx.x & 63, q = lane & 3, lg = lane >> 2;
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t g0 = unit * (16 * NG);
+  if (g0 >= a.B) return;
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.state, 0, static_cast<int>(a.B * a.stride), 0x00027000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(a.done, 0, 0x7fffffff, 0x00027000);
+  uint4 pk[NG];
+  int64_t g[NG];
+  bool live[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) {
+    g[n] = g0 + 16 * n + lg;
+    live[n] = g[n] < a.B;
+    if (!live[n]) g[n] = a.B - 1;  // dead lanes shadow the last game, stores predicated off
+    pk[n] = *reinterpret_cast<const uint4*>(a.state + g[n] * a.stride + 16 * q);
+  }
+  for (int k = 0; k < a.K; ++k) {
+    if (a.ready) {  // relaxed agent-scope poll (bypasses this CU's L1), one address for the wavefront
+      uint32_t spins = 0;
+      while (__hip_atomic_load(a.ready + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        if (++spins >= a.spin_limit) {  // wave-uniform (same address, same value in every lane)
+          if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    const int8_t* blk = a.actions + static_cast<int64_t>(k) * a.B * 12;
+    uint8_t* dn = a.done + static_cast<int64_t>(k) * a.B;
+    (void)dn;
+#pragma unroll
+    for (int n = 0; n < NG; ++n) {
+      const int* tp = reinterpret_cast<const int*>(blk + g[n] * 12);
+      // sc1 loads: the tokens were written by another agent after this CU may have cached the lines (ring reuse)
+      const uint32_t du = static_cast<uint32_t>(__hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const uint32_t dv = static_cast<uint32_t>(__hip_atomic_load(tp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const uint32_t dw = static_cast<uint32_t>(__hip_atomic_load(tp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      uint32_t nz = 0;
+      int ovf = 0;
+      pk[n] = s4_step_slice(pk[n], du, dv, dw, q, a.shift, nz, ovf);
+      const bool any_nz = team_any<4>(nz != 0);
+      const bool any_ovf = team_any<4>((ovf & ~255) != 0);
+      if (live[n]) {  // write-through (sc1) stores: visible to other agents once this wavefront's vmcnt drains
+        typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(tg_u32x4{pk[n].x, pk[n].y, pk[n].z, pk[n].w}, srs,
+                                               static_cast<int>(g[n] * a.stride) + 16 * q, 0, 16);
+        if (q == 0) {
+          __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(any_nz ? 0 : 1), drs,
+                                               static_cast<int>(static_cast<int64_t>(k) * a.B + g[n]), 0, 16);
+          if (a.overflow && any_ovf) a.overflow[g[n]] = 1;
+        }
+      }
+    }
+    if (a.progress) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores of step k have left
+      if (lane == 0) __hip_atomic_store(a.progress + unit, static_cast<uint32_t>(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// =============================================================================================
 // S = 16 single step, register only.  One wavefront per game; lane = (r, j) owns the four rows
 // (i = r + 4n, j), n = 0..3, i.e. chunks lane + 64 n.  The game's 48 tokens come straight into
 // registers (u and w as uniform dwordx4 loads, v_j as a byte), so there is no LDS staging and no
@@ -1300,6 +1388,51 @@ int tg_step_sparse_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_
   return launch_apply<tg::STEPS>("tg_step_sparse_i8", a, static_cast<hipStream_t>(stream));
 }
 #endif  // TG_AB_SWITCHES
+
+/* units (wavefronts) and games per unit of tg_step_stream_i8 for a batch of B games, or a negative TG_ERR_* */
+int tg_step_stream_layout(int64_t B, int S, int64_t* n_units, int* games_per_unit) {
+  if (B < 0) return fail(TG_ERR_INVALID, "tg_step_stream_layout: B < 0");
+  if (S != 4) return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: S=%d (the streamed stepper is built for S=4)", S);
+  // every wavefront must be resident at once when the producer waits for the whole batch: 8 workgroups of 4
+  // wavefronts per CU at most, so larger batches give each wavefront more games (16 NG, NG <= 8)
+  const int64_t cap = static_cast<int64_t>(device_cu_count()) * 32;
+  int ng = 1;
+  while (ng < 8 && (B + 16 * ng - 1) / (16 * ng) > cap) ng *= 2;
+  if ((B + 16 * ng - 1) / (16 * ng) > cap)
+    return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: B=%lld exceeds %lld games resident at once", (long long)B, (long long)(cap * 128));
+  if (n_units) *n_units = (B + 16 * ng - 1) / (16 * ng);
+  if (games_per_unit) *games_per_unit = 16 * ng;
+  return TG_OK;
+}
+
+int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8_t* overflow, const uint32_t* ready,
+                      uint32_t* progress, uint32_t* status, int64_t B, int S, int K, int64_t game_stride_bytes, int shift,
+                      tg_stream_t stream) {
+  const char* fn = "tg_step_stream_i8";
+  if (int rc = validate_common(fn, B, S, game_stride_bytes)) return rc;
+  if (K < 1 || K > (1 << 24)) return fail(TG_ERR_INVALID, "%s: K=%d outside [1,2^24]", fn, K);
+  if (B == 0) return TG_OK;
+  if (!state || !actions || !done) return fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  int64_t units = 0;
+  int gpu_ = 0;
+  if (int rc = tg_step_stream_layout(B, S, &units, &gpu_)) return rc;
+  if (!aligned16(state) || game_stride_bytes % 16 != 0 || !aligned4(actions) || B * game_stride_bytes > 0x7fffffffLL ||
+      static_cast<int64_t>(K) * B > 0x7fffffffLL || static_cast<unsigned>(shift + 127) > 254u)
+    return fail(TG_ERR_UNSUPPORTED, "%s: needs 16-byte aligned states, 4-byte aligned actions, B*stride and K*B < 2^31, |shift| <= 127", fn);
+  if ((ready && (reinterpret_cast<uintptr_t>(ready) & 3)) || (progress && (reinterpret_cast<uintptr_t>(progress) & 3)))
+    return fail(TG_ERR_INVALID, "%s: ready / progress must be 4-byte aligned", fn);
+  tg::StreamArgs a{state, actions, done, overflow, ready, progress, status, B, game_stride_bytes, K, shift, 1u << 22};
+  const unsigned grid = static_cast<unsigned>((units + 3) / 4);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  (void)hipGetLastError();
+  switch (gpu_ / 16) {
+    case 1: hipLaunchKernelGGL(tg::s4_stream_kernel<1>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(tg::s4_stream_kernel<2>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(tg::s4_stream_kernel<4>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
+    default: hipLaunchKernelGGL(tg::s4_stream_kernel<8>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
+  }
+  return check_launch(fn);
+}
 
 int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
                     int32_t* done_step, uint8_t* overflow, int64_t B, int S, int K,

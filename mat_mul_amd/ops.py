@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import TG_MAX_ACTIONS, TG_MAX_S, TG_MAX_VALUES, TensorGameError, call
 
 __all__ = [
-    "step", "step_sparse", "copy_states", "prepare_step", "step_many", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
+    "step", "step_sparse", "copy_states", "prepare_step", "step_many", "step_stream", "step_stream_layout", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
     "gen_demos", "sample_basis", "change_basis", "as_tokens", "categorical_thresholds",
     "alloc_states", "alloc_ring", "emit_frames", "state_hash", "slice_rank",
 ]
@@ -203,6 +203,41 @@ def step_many(state, actions, out=None, done_step=None, overflow=None, shift: in
         call("tg_step_many_i8", _ptr(state), _ptr(out), _ptr(actions), _ptr(done_step), _ptr(overflow),
              B, S, K, stride, int(shift), _stream(dev))
     return out, done_step
+
+
+def step_stream_layout(B: int, S: int, device=None) -> Tuple[int, int]:
+    """(n_units, games_per_unit) of ``step_stream``: unit u (a wavefront) owns games [u*gpu, (u+1)*gpu)."""
+    n, g = C.c_int64(0), C.c_int(0)
+    with torch.cuda.device(torch.device(device) if device is not None else torch.cuda.current_device()):
+        call("tg_step_stream_layout", B, S, C.byref(n), C.byref(g))
+    return int(n.value), int(g.value)
+
+
+def step_stream(state, actions, done=None, overflow=None, ready=None, progress=None, status=None, shift: int = 1):
+    """K in-place steps in ONE launch for action blocks that become available step by step.
+    actions int8 (K,B,3S) STEP-major; ready uint32/int32 (K) (step k waits for ready[k] != 0) or None;
+    done uint8 (K,B); progress int32 (n_units); status int32 (1).  == K calls of ``step(state, actions[k], out=state)``
+    without the launch boundary between them.  Returns (state, done)."""
+    B, S, stride = _state_layout(state, "state")
+    dev = state.device
+    if actions.dim() != 3:
+        raise TensorGameError("step_stream", -1, "actions must be (K,B,3S), step-major")
+    K = actions.shape[0]
+    actions = _tokens(actions, (K, B), S, dev, "actions")
+    if done is None:
+        done = torch.empty((K, B), dtype=torch.uint8, device=dev)
+    done = _flag(done, (K, B), torch.uint8, dev, "done")
+    overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
+    for name, t, n in (("ready", ready, K), ("progress", progress, None), ("status", status, 1)):
+        if t is not None and (t.dtype not in (torch.int32, torch.uint32) or t.dim() != 1 or not t.is_contiguous()
+                              or (n is not None and t.numel() != n) or (t.device != dev and not t.is_pinned())):
+            raise TensorGameError("step_stream", -1, f"{name} must be a contiguous 32-bit vector on {dev}")
+    if progress is not None and progress.numel() < step_stream_layout(B, S, dev)[0]:
+        raise TensorGameError("step_stream", -1, "progress needs one word per unit (ops.step_stream_layout)")
+    with torch.cuda.device(dev):
+        call("tg_step_stream_i8", _ptr(state), _ptr(actions), _ptr(done), _ptr(overflow), _ptr(ready), _ptr(progress),
+             _ptr(status), B, S, K, stride, int(shift), _stream(dev))
+    return state, done
 
 
 def expand(state, actions, out=None, done=None, changed=None, overflow=None, shift: int = 1):

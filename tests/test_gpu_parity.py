@@ -1072,3 +1072,80 @@ def test_bench_two_ranks_self_launched_on_one_gpu(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 20 and out["samples"] == 9
     assert out["config"]["global_batch"] == 131072 and out["config"]["batch_per_gpu"] == 65536
     assert out["value"] > 1e9 and 0 < out["roofline"]["frac"] <= 1.0
+
+
+# ------------------------------------------------------------------ tg_step_stream_i8 (K steps, one launch, actions arriving step by step)
+@pytest.mark.parametrize("B,K", [(1, 3), (16, 5), (70, 9), (1000, 14), (4099, 6)])
+def test_step_stream_equals_k_single_steps(B, K):
+    """Every step of the streamed stepper equals tg_step_i8 / the oracle: state, done[k], sticky overflow; ragged
+    batches, terminal games, an overflowing game, progress words; padded and packed layouts."""
+    rng = np.random.default_rng(B * 31 + K)
+    S = 4
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(K, B, 3 * S)).astype(np.int8)
+    st[::5] = O.action_to_tensor(ac[0, ::5]).astype(np.int8)              # these are done after step 0
+    if B > 3:
+        st[3] = 127
+        ac[1, 3] = 0                                                       # factors -1: 127 - (-1) overflows at step 1
+    want_done, want_ovf, cur = np.zeros((K, B), np.uint8), np.zeros(B, np.uint8), st.copy()
+    for k in range(K):
+        cur, d, o = O.step_i8(cur, ac[k])
+        want_done[k] = d
+        want_ovf |= o
+    n_units, gpu = ops.step_stream_layout(B, S, DEV)
+    assert n_units * gpu >= B and (n_units - 1) * gpu < B
+    for t in (padded(st), dev(st)):
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        prog = torch.zeros(n_units, dtype=torch.int32, device=DEV)
+        status = torch.zeros(1, dtype=torch.int32, device=DEV)
+        out, done = ops.step_stream(t, dev(ac), overflow=ovf, progress=prog, status=status)
+        torch.cuda.synchronize()
+        assert out.data_ptr() == t.data_ptr()
+        assert np.array_equal(host(t), cur) and np.array_equal(host(done), want_done) and np.array_equal(host(ovf), want_ovf)
+        assert bool((prog == K).all()) and int(status[0]) == 0
+    assert want_done[0, ::5].all() and (B <= 3 or want_ovf[3] == 1)
+
+
+def test_step_stream_waits_for_ready_words_and_times_out():
+    """The stepper polls ready[k]: released one by one from a second stream while the kernel is resident, every step
+    still equals the oracle; with a ready word that never arrives the bounded spin gives up and sets status."""
+    rng = np.random.default_rng(8)
+    B, K, S = 300, 6, 4
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(K, B, 3 * S)).astype(np.int8)
+    cur = st.copy()
+    for k in range(K):
+        cur, _, _ = O.step_i8(cur, ac[k])
+    t = padded(st)
+    ready = torch.zeros(K, dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    n_units, _ = ops.step_stream_layout(B, S, DEV)
+    prog = torch.zeros(n_units, dtype=torch.int32, device=DEV)
+    acd = dev(ac)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ops.step_stream(t, acd, ready=ready, progress=prog, status=status)
+    for k in range(K):                                                     # the producer: the default stream
+        ready[k:k + 1].fill_(1)
+        torch.cuda.current_stream().synchronize()
+    side.synchronize()
+    assert int(status[0]) == 0 and np.array_equal(host(t), cur) and bool((prog == K).all())
+    # never released: every wavefront gives up after its bounded spin, the state stops where the words stopped
+    t2 = padded(st)
+    ready.zero_()
+    ready[:2] = 1
+    status.zero_()
+    ops.step_stream(t2, acd, ready=ready, status=status)
+    torch.cuda.synchronize()
+    two = st.copy()
+    for k in range(2):
+        two, _, _ = O.step_i8(two, ac[k])
+    assert int(status[0]) == 1 and np.array_equal(host(t2), two)
+
+
+def test_step_stream_refuses_what_it_does_not_implement():
+    t = ops.alloc_states(8, 16, DEV)
+    with pytest.raises(mat_mul_amd.TensorGameError, match="S=4"):
+        ops.step_stream(t, torch.ones((2, 8, 48), dtype=torch.int8, device=DEV))
+    assert ops.step_stream_layout(1 << 20, 4, DEV)[1] in (16, 32, 64, 128)
