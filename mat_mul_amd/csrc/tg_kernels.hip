@@ -544,11 +544,10 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
       // holes inside 64-byte games turn full-line writes into partial ones -- 2.83 -> 3.05 us at cfg2)
       if (live) *reinterpret_cast<uint4*>(out_blk + out_off) = pk;
       const bool any_nz = team_any<4>(nz != 0);
-      const bool any_ovf = team_any<4>((ovf & ~255) != 0);
-      if (q == 0 && live) {
-        (a.done + g0)[lg] = any_nz ? 0 : 1;
-        if (a.overflow && any_ovf) (a.overflow + g0)[lg] = 1;
-      }
+      if (q == 0 && live) (a.done + g0)[lg] = any_nz ? 0 : 1;
+      // the flag is sticky and only ever set to 1: a lane whose slice overflowed stores it itself (rare), so the
+      // common path carries no team reduction for it
+      if (__builtin_expect((ovf & ~255) != 0, 0) && a.overflow && live) (a.overflow + g0)[lg] = 1;
       if constexpr (MODE == STEPS) {  // S=4 reads the whole game anyway: nnz is simply recounted
         int cnt = count_nonzero_bytes(pk);
         cnt += __shfl_xor(cnt, 1);
