@@ -57,6 +57,10 @@ const char* tg_last_error(void);
 /* Debug: number of workgroups so far (this process, current device) that left the packed 16-bit
  * fast path for the exact byte-wise form.  SYNCHRONISES the device; not for hot loops. */
 int tg_debug_fallbacks(uint64_t* count);
+/* Debug: number of games so far that the matrix-core pass of tg_step_many_i8 could not certify (a step may have
+ * left int8, or the zero state was reached before the last step) and handed to the exact lattice kernels.
+ * SYNCHRONISES the device; not for hot loops. */
+int tg_debug_handovers(uint64_t* count);
 
 /* ---- the env step ------------------------------------------------------------------------- */
 

@@ -34,6 +34,7 @@ SIGNATURES = {
     "tg_abi_version": [],
     "tg_last_error": [],
     "tg_debug_fallbacks": [_p],
+    "tg_debug_handovers": [_p],
     "tg_step_i8": [_p, _p, _p, _p, _p, _i64, _i, _i64, _i, _p],
     "tg_step_many_i8": [_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _p],
     "tg_step_stream_i8": [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _p],

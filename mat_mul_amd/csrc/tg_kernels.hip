@@ -43,6 +43,9 @@ __device__ unsigned long long g_fallback_workgroups = 0;
 __device__ __forceinline__ void note_fallback() {
   if (threadIdx.x == 0) atomicAdd(&g_fallback_workgroups, 1ull);
 }
+// Debug aid: games the matrix-core pass of tg_step_many_i8 could not certify and handed to the lattice kernels
+// (each costs a second pass; the reference's {-1,0,1} and the paper's {-2..2} vocabularies should stay at 0).
+__device__ unsigned long long g_many_handovers = 0;
 
 struct ApplyArgs {
   const int8_t* in;      // GENF: unused (state starts at zero)
@@ -1218,7 +1221,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     // per-action scalars, verdict) outweighs the lattice kernels' K S^3 MACs only for long action lists; beyond
     // K = 127 the overflow bound cannot certify the reference's {-1,0,1} factors any more.
     const bool many_always = TG_SWITCH("TG_MFMA_MANY_ALWAYS");  // tests: every eligible shape
-    const bool pays = a.nact <= 127 && ((a.S == 25 && a.nact >= 12) || (a.S == 16 && a.nact >= 40) || (a.S == 9 && a.nact >= 48));
+    const bool pays = (a.S == 25 && a.nact >= 12) || (a.S == 16 && a.nact >= 40) || (a.S == 9 && a.nact >= 48);  // up to 256
     if (al && a.nact <= 256 && !force_i32 && !no_mfma && (a.S == 9 || a.S == 16 || a.S == 25) && (pays || many_always)) {
       const int Rp = (a.nact + 31) & ~31;
 #define TG_MANY_K(S_, KS_)                                                                       \
@@ -1360,6 +1363,14 @@ int tg_debug_fallbacks(uint64_t* count) {
   unsigned long long v = 0;
   hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(tg::g_fallback_workgroups), sizeof(v));
   if (e != hipSuccess) return fail(TG_ERR_HIP, "tg_debug_fallbacks: %s", hipGetErrorString(e));
+  *count = v;
+  return TG_OK;
+}
+int tg_debug_handovers(uint64_t* count) {
+  if (!count) return fail(TG_ERR_INVALID, "tg_debug_handovers: null pointer");
+  unsigned long long v = 0;
+  hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(tg::g_many_handovers), sizeof(v));
+  if (e != hipSuccess) return fail(TG_ERR_HIP, "tg_debug_handovers: %s", hipGetErrorString(e));
   *count = v;
   return TG_OK;
 }

@@ -305,9 +305,13 @@ __global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) 
 //     P_k = 0 implies h(P_k) = 0, so the first zero state is the first k where both functionals vanish --
 //     or a false positive (probability ~2^-64).  A candidate at k = K-1 is checked against the final
 //     state, which is already there.
-// Games that fail the bound, have a candidate before K-1, or have factors beyond the byte-product range
+//     That scalar bound costs nothing but is coarse (K <= 127 for {-1,0,1}; the paper's {-2..2} fails it at once).
+//     Games that fail it take the ELEMENTWISE bound |P_k[e]| <= |X0[e]| + sum_r |u_r[i]| |v_r[j]| |w_r[l]|: one more
+//     pass over the tiles, the same accumulation on the absolute values (|T| copied next to T, |X0| through an
+//     identity fragment), only the maximum is kept.  If it is <= 127 everywhere no prefix left int8.
+// Games that fail both bounds, have a candidate before K-1, or have factors beyond the byte-product range
 // are NOT written: their done_step is set to kNeedsExact and the lattice kernels (tg_rows.h / tg_packed.h),
-// launched right after with ApplyArgs::only_flagged, redo exactly those games.
+// launched right after with ApplyArgs::only_flagged, redo exactly those games (counted in g_many_handovers).
 // =============================================================================================
 // inclusive prefix sum over the 64 lanes of a wavefront, all in the VALU (DPP row shifts and row broadcasts)
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
@@ -344,7 +348,13 @@ __constant__ FunctionalWeights g_fw = make_functional_weights();
 
 template <int S>
 constexpr int many_mfma_lds_bytes(int Rp) {
-  return MGeo<S>::TROWS * (Rp + 16) + MGeo<S>::IMG + 32 + 32 + 8 * MGeo<S>::NT * 32 + 36 * Rp;
+  return 2 * MGeo<S>::TROWS * (Rp + 16) + MGeo<S>::IMG + 32 + 32 + 8 * MGeo<S>::NT * 32 + 36 * Rp;
+}
+
+// |x| of four packed int8 (-128 stays 0x80: callers exclude it)
+__device__ __forceinline__ uint32_t abs4_i8(uint32_t x) {
+  const uint32_t s1 = (x >> 7) & 0x01010101u;
+  return (x ^ (s1 * 0xFFu)) + s1;
 }
 
 template <int S, int KS>
@@ -360,6 +370,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
   uint32_t* const cw = reinterpret_cast<uint32_t*>(red + 8);    // [2][NT*32] column weights pu[i] pv[j]
   int* const sdot = reinterpret_cast<int*>(cw + 2 * G::NT * 32);  // [2][3][Rp]
   int* const smx = sdot + 6 * Rp;                                 // [3][Rp]
+  int8_t* const Tabs = reinterpret_cast<int8_t*>(smx + 3 * Rp);   // |T|, same layout (filled for games on the elementwise bound)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
   const int R = a.nact;
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
   constexpr int NRG = kBlock / G::A3;
   constexpr int TB = 6;
   const int sx = tid % G::A3, srg = tid / G::A3;
-  const int slo = sx < 2 * S ? -G::UVLIM : -128, shi = sx < 2 * S ? G::UVLIM : 127;
+  const int slo = sx < 2 * S ? -G::UVLIM : -127, shi = sx < 2 * S ? G::UVLIM : 127;  // (w = -128 has no int8 |w|)
 
   constexpr int NW = kBlock / 64, TPW = (G::NT + NW - 1) / NW;
   int uoff[TPW], voff[TPW], ncol[TPW], xoff[TPW];
@@ -406,6 +417,9 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
     ida[d] = static_cast<int>(w);
   }
   constexpr int kF0 = (S & 3) + 4 * (S >> 3), kF1 = ((S + 1) & 3) + 4 * ((S + 1) >> 3);  // registers of rows S, S+1 (h = 0)
+  v4i idp;  // the plain identity (rows >= S zero): |X0| enters the bound pass through it
+#pragma unroll
+  for (int d = 0; d < 4; ++d) idp[d] = col < S ? ida[d] : 0;
 
   for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
     // ---- 1. factors (u negated: the products are subtracted), transposed into LDS; X0 into the image ----
@@ -444,7 +458,10 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
     }
     if (tid < 8) red[tid] = 0;
     if (__syncthreads_or(big)) {  // factors beyond the byte products: the lattice kernels take this game
-      if (tid == 0) a.done_step[g] = kNeedsExact;
+      if (tid == 0) {
+        a.done_step[g] = kNeedsExact;
+        atomicAdd(&g_many_handovers, 1ull);
+      }
       __syncthreads();
       continue;
     }
@@ -480,10 +497,63 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       bound += static_cast<int>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_scan(static_cast<uint32_t>(pb))), 63));
       if (bound > (1 << 24)) bound = 1 << 24;
     }
-    if (bound > 127) {  // workgroup-uniform
-      if (tid == 0) a.done_step[g] = kNeedsExact;
+    const bool wide = bound > 127;  // workgroup-uniform: the scalar bound cannot certify this game
+    if (wide) {
+      // ---- elementwise bound: Bnd = |X0| + sum_r |u_r| (x) |v_r| (x) |w_r|, the same tiles on absolute values ----
+      for (int e = 16 * tid; e < G::TROWS * RS; e += 16 * kBlock) {
+        const uint4 q = *reinterpret_cast<const uint4*>(T + e);
+        *reinterpret_cast<uint4*>(Tabs + e) = uint4{abs4_i8(q.x), abs4_i8(q.y), abs4_i8(q.z), abs4_i8(q.w)};
+      }
       __syncthreads();
-      continue;
+      int bmax = 0;
+      uint32_t m128 = 0;  // a byte 0x80 in |X0|: the start state holds -128, whose bound is 128 > 127 anyway
+#pragma unroll 1
+      for (int k = 0; k < TPW; ++k) {
+        if (G::NT % NW != 0 && wave + NW * k >= G::NT) break;  // wave-uniform
+        v16i acc;
+#pragma unroll
+        for (int t2 = 0; t2 < 16; ++t2) acc[t2] = 0;
+        {
+          const int m = xoff[k] & 3;
+          const uint32_t* p4 = reinterpret_cast<const uint32_t*>(img + (xoff[k] & ~3));
+          uint32_t d[5];
+#pragma unroll
+          for (int t = 0; t < 5; ++t) d[t] = p4[t];
+          v4i xf;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const uint32_t ax = abs4_i8(__builtin_amdgcn_alignbyte(d[t + 1], d[t], static_cast<uint32_t>(m)));
+            // only bytes k = 16 h + 4 t + b < S belong to this lane's column (the rest meets zero rows of the identity
+            // and may lie beyond the image)
+            const int nvb = S - (16 * h + 4 * t);
+            const uint32_t vb = nvb >= 4 ? 0x80808080u : (nvb <= 0 ? 0u : (0x80808080u >> (8 * (4 - nvb))));
+            if (ncol[k] >= 0) m128 |= ax & vb;
+            xf[t] = static_cast<int>(ax);
+          }
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(idp, xf, acc, 0, 0, 0);
+        }
+        for (int k0 = 0; k0 < Rp; k0 += 32) {
+          const v4i w = *reinterpret_cast<const v4i*>(Tabs + woff + k0);
+          const v4i p = bytemul16(*reinterpret_cast<const v4i*>(Tabs + uoff[k] + k0),
+                                  *reinterpret_cast<const v4i*>(Tabs + voff[k] + k0));
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, p, acc, 0, 0, 0);
+        }
+        if (ncol[k] >= 0) {
+#pragma unroll
+          for (int t2 = 0; t2 < 16; t2 += 2) bmax = max(max(acc[t2], acc[t2 + 1]), bmax);
+        }
+      }
+      if (m128) bmax = 128;
+      if (bmax) atomicMax(&red[3], bmax);
+      __syncthreads();
+      if (red[3] > 127) {  // workgroup-uniform: some prefix may leave int8 -- the lattice kernels decide exactly
+        if (tid == 0) {
+          a.done_step[g] = kNeedsExact;
+          atomicAdd(&g_many_handovers, 1ull);
+        }
+        __syncthreads();
+        continue;
+      }
     }
 
     // ---- 2b. column tiles: acc = I X0 + W P ----
@@ -606,7 +676,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
         carry1 += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(g1), 63));
       }
       const bool final_zero = maxfinal == 0;
-      redo = maxfinal + bound > 127;                           // a step may have left int8
+      redo = !wide && maxfinal + bound > 127;                  // a step may have left int8 (wide: certified elementwise above)
       redo |= first >= 0 && first < R - 1;                     // a candidate that the final state cannot confirm
       redo |= final_zero && first != R - 1;                    // cannot happen; never trust it silently
       dstep = (first == R - 1 && final_zero) ? R - 1 : -1;
@@ -616,7 +686,10 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       for (int c = tid; c < G::NCHUNK; c += kBlock)
         store_chunk<G::TAIL>(out + 16 * c, *reinterpret_cast<const uint4*>(img + 16 * c), c == G::NCHUNK - 1);
     }
-    if (tid == 0) a.done_step[g] = redo ? kNeedsExact : dstep;
+    if (tid == 0) {
+      a.done_step[g] = redo ? kNeedsExact : dstep;
+      if (redo) atomicAdd(&g_many_handovers, 1ull);
+    }
     __syncthreads();
   }
 }

@@ -488,3 +488,11 @@ def debug_fallbacks(device="cuda:0") -> int:
     with torch.cuda.device(torch.device(device)):
         call("tg_debug_fallbacks", C.byref(out))
     return int(out.value)
+
+
+def debug_handovers(device="cuda:0") -> int:
+    """Games the matrix-core pass of step_many handed to the lattice kernels so far (debug counter; synchronises)."""
+    out = C.c_uint64(0)
+    with torch.cuda.device(torch.device(device)):
+        call("tg_debug_handovers", C.byref(out))
+    return int(out.value)

@@ -255,7 +255,8 @@ def test_step_many_matrix_core_path_verdicts(S, K):
     ac[14, 1, 0] = 13
     # 15: full int8 w
     ac[15, 2, 2 * S:] = rng.integers(-127, 128, size=S)
-    # 16..17: {-2..2} vocabulary: the scalar bound fails, the lattice kernels certify
+    # 16..17: dense {-2..2} factors: the scalar bound fails; the elementwise bound certifies short lists, the lattice
+    # kernels the rest
     ac[16:18] = rng.integers(-1, 4, size=(2, K, 3 * S))
     # 18: passes through zero at step 5 and leaves again
     st[18] = O.gen_from_factors_i8(ac[18:19, :6], 1)[0][0]
@@ -270,6 +271,45 @@ def test_step_many_matrix_core_path_verdicts(S, K):
     ovf.zero_()
     ops.step_many(t, dev(ac), out=t, overflow=ovf)
     assert np.array_equal(host(t), want) and np.array_equal(host(ovf), want_ovf)
+
+
+@pytest.mark.parametrize("S,K,values,probs", [
+    (25, 64, (-2, -1, 0, 1, 2), (0.05, 0.1, 0.7, 0.1, 0.05)),   # the paper's vocabulary at BASELINE config 5's length
+    (16, 64, (-2, -1, 0, 1, 2), (0.05, 0.1, 0.7, 0.1, 0.05)),
+    (25, 200, (-1, 0, 1), (0.15, 0.7, 0.15)),                   # K > 127: beyond the scalar bound for any vocabulary
+    (16, 256, (-1, 0, 1), (0.15, 0.7, 0.15)),
+    (9, 130, (-1, 0, 1), (0.15, 0.7, 0.15)),
+])
+def test_step_many_elementwise_bound_keeps_games_on_the_matrix_cores(S, K, values, probs):
+    """the scalar overflow bound (max|final| + sum of max|u| max|v| max|w|) hands every {-2..2} game and
+    every list beyond 127 actions to the lattice kernels; the elementwise bound |X0| + sum |u||v||w| certifies them on the
+    matrix cores.  Demo replays: exact results, and NOT ONE game handed over."""
+    B = 40
+    thr = O.categorical_thresholds(probs)
+    tok, tgt, ovf0 = O.gen_demos_i8(B, S, K, thr, values, 1, seed=3 * S + K)
+    keep = ovf0 == 0
+    tok, tgt = tok[keep], tgt[keep]
+    assert len(tok) >= B // 2
+    want, want_ds, want_ovf = O.step_many_i8(tgt, tok)
+    assert not want.any() and not want_ovf.any()
+    before_h, before_f = ops.debug_handovers(DEV), ops.debug_fallbacks(DEV)
+    ovf = torch.zeros(len(tok), dtype=torch.uint8, device=DEV)
+    out, ds = ops.step_many(padded(tgt), dev(tok), overflow=ovf)
+    assert np.array_equal(host(out), want) and np.array_equal(host(ds), want_ds) and not host(ovf).any()
+    early = int((want_ds != K - 1).sum())           # a replay whose last terms cancel is done early: that one is redone
+    assert ops.debug_handovers(DEV) - before_h == early and early <= 2
+    assert ops.debug_fallbacks(DEV) == before_f
+    # and a game that does overflow in the middle is still caught: dense +-2 action and its negation
+    tok2, tgt2 = tok[:4].copy(), tgt[:4].copy()
+    tok2[:, 1] = -1                                   # u = v = w = -2 everywhere: every entry + 8
+    tok2[:, 2] = tok2[:, 1]
+    tok2[:, 2, :S] = 3                                # ... and back
+    tgt2[:] = 125
+    w2, wds2, wovf2 = O.step_many_i8(tgt2, tok2)
+    assert wovf2.all()
+    ovf2 = torch.zeros(4, dtype=torch.uint8, device=DEV)
+    o2, ds2 = ops.step_many(padded(tgt2), dev(tok2), overflow=ovf2)
+    assert np.array_equal(host(o2), w2) and np.array_equal(host(ds2), wds2) and np.array_equal(host(ovf2), wovf2)
 
 
 @pytest.mark.parametrize("S", [9, 16, 25])
