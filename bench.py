@@ -608,8 +608,7 @@ def also_lines(S_main, B_main, dev, mode):
                      "us_per_launch": round(sec * 1e6, 2), "GBps": round(nbytes / sec / 1e9, 1)})
     # the streamed stepper (its own entry and metric): K steps in ONE resident launch, the state stays in registers,
     # per step poll + 12 token bytes in + state and done written through + a progress word per wavefront
-    for (b2, k2) in [(65536, 1008), (131072, 504)]:
-        s2, r2 = 4, 7
+    for (s2, b2, k2, r2) in [(4, 65536, 1008, 7), (4, 131072, 504, 7), (16, 8192, 512, 8)]:
         tok, tgt = ops.gen_demos(b2, s2, r2, dev, seed=4)
         cyc = torch.cat([tok, tok], dim=1)
         cyc[:, r2:, :s2] = 2 - cyc[:, r2:, :s2]                  # the same terms with u negated: period 14
@@ -634,14 +633,18 @@ def also_lines(S_main, B_main, dev, mode):
         sec = statistics.median(ts)
         ok = bool(torch.equal(st2, tgt)) and int(status[0]) == 0 and bool((prog == k2).all()) \
             and bool(dn[r2 - 1].all()) and not bool(dn[0].all())
-        moved = b2 * (s2 ** 3 + 3 * s2 + 1)                       # per step: tokens in, state + done out (no state read)
+        # per step: tokens in, done out, and the state written through (S=16: only the 16-byte rows an action changes)
+        moved = b2 * (s2 ** 3 + 3 * s2 + 1) if s2 == 4 else \
+            b2 * (3 * s2 + 1) + 16.0 * changed_chunks_per_launch(s2, [acts[k] for k in range(2 * r2)])
         also.append({"workload": f"STREAMED tg_step_stream_i8: S={s2} batch={b2}, K={k2} steps in ONE launch, actions "
                                  f"consumed step by step (ready words pre-set), progress published per wavefront; "
                                  f"not the single-step metric",
                      "ok": ok, "value": round(b2 * k2 / sec, 1), "unit": "steps/s", "us_per_step": round(sec / k2 * 1e6, 3),
                      "GBps_moved": round(moved * k2 / sec / 1e9, 1),
                      "frac_of_hbm_peak_moved_bytes": round(moved * k2 / sec / 1e9 / HBM_PEAK_GBS, 4),
-                     "note": "bytes moved per step = S^3 + 3S + 1 per game (the state is not re-read: it lives in registers)"})
+                     "launch_per_step_us": None,
+                     "note": "bytes moved per step: tokens in, done + state out (S=16: changed rows only); the state is "
+                             "not re-read, it lives in registers"})
         del acts, dn
     # BASELINE config 5's generator (per-GPU share: 4 096 demos, S=25, R=64), with and without the change
     # of basis; bytes = target + tokens written (S^3 + 3SR per demo); replayed as a hipGraph

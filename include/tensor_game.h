@@ -106,9 +106,12 @@ int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* act
  *   [u*games_per_unit, (u+1)*games_per_unit) (tg_step_stream_layout); once the state and done[k] of its games are
  *   visible to other agents (write-through stores, drained) unit u stores k+1 into progress[u].
  *   status: uint32 (1) or NULL, set to 1 if a wavefront gave up waiting for a ready word (bounded spin, ~1 s).
- * No wavefront ever waits for another one, so the launch cannot deadlock on residency.  S = 4 only in this build
- * (TG_ERR_UNSUPPORTED otherwise), states 16-byte aligned.  This is a separate entry with its own metric: the
- * single-step figures of tg_step_i8 never include it. */
+ * No wavefront ever waits for another one, so the launch itself cannot deadlock; a producer that waits for the WHOLE
+ * batch before releasing the next step additionally needs every unit resident at once: S = 4 up to 2^20 games on 256
+ * CUs (tg_step_stream_layout refuses more), S = 16 (one wavefront per game, the 4 KiB of a game in registers) up to
+ * 32 games per CU = 8 192 on 256 CUs.  S = 4 and S = 16 in this build (TG_ERR_UNSUPPORTED otherwise), states 16-byte
+ * aligned (S = 16: actions too).  This is a separate entry with its own metric: the single-step figures of tg_step_i8
+ * never include it. */
 int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8_t* overflow,
                       const uint32_t* ready, uint32_t* progress, uint32_t* status, int64_t B, int S, int K,
                       int64_t game_stride_bytes, int shift, tg_stream_t stream);

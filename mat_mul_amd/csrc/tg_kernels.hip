@@ -927,6 +927,99 @@ __global__ __launch_bounds__(kBlock) void s16_step_kernel(ApplyArgs a) {
 }
 
 // =============================================================================================
+// tg_step_stream_i8, S = 16: one wavefront per game, the game's 4 KiB live in 16 VGPRs per lane for all K steps (lane
+// (r, j) owns rows (i = r + 4 n, j), as in s16_step_kernel).  A step reads 48 token bytes and writes through only the
+// rows the action changed (9 % with the reference's vocabulary) plus `done`: the launch-per-step kernel re-reads
+// 32 MiB per step at BASELINE config 3, this one moves ~3 MB.  8192 games = 32 wavefronts per CU on 256 CUs: all
+// resident at <= 64 VGPRs (__launch_bounds__(256, 8)).
+// =============================================================================================
+__global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  // the game index is wave-uniform; say so (readfirstlane), or hipcc wraps every access through the per-game token
+  // descriptor in a waterfall loop
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  if (g >= a.B) return;
+  const int r = lane >> 4;
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.state, 0, static_cast<int>(a.B * a.stride), 0x00027000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(a.done, 0, 0x7fffffff, 0x00027000);
+  const int soff = static_cast<int>(g * a.stride) + 16 * lane;
+  uint4 par[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) par[n] = *reinterpret_cast<const uint4*>(a.state + g * a.stride + 16 * lane + 1024 * n);
+  const uint32_t shp = (static_cast<uint32_t>(a.shift) & 0xFFFFu) | (static_cast<uint32_t>(a.shift) << 16);
+  for (int k = 0; k < a.K; ++k) {
+    if (a.ready) {
+      uint32_t spins = 0;
+      while (__hip_atomic_load(a.ready + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        if (++spins >= a.spin_limit) {
+          if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    // the step's 48 tokens, sc1 (written by another agent): u and w as 16 bytes each, v_j as this lane's byte
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int8_t*>(a.actions + (static_cast<int64_t>(k) * a.B + g) * 48), 0, 48, 0x00027000);
+    const u32x4 uq = __builtin_amdgcn_raw_buffer_load_b128(trs, 0, 0, 16);
+    const u32x4 wq = __builtin_amdgcn_raw_buffer_load_b128(trs, 32, 0, 16);
+    const int vj = static_cast<int8_t>(__builtin_amdgcn_raw_buffer_load_b8(trs, 16 + (lane & 15), 0, 16)) - a.shift;
+    uint32_t wp[8];
+    unpack_pairs(uint4{wq[0], wq[1], wq[2], wq[3]}, wp);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
+    const uint32_t vjp = __builtin_amdgcn_perm(static_cast<uint32_t>(vj), static_cast<uint32_t>(vj), 0x05040100u);
+    uint32_t nz = 0, ovf = 0;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(uq[n]), 8 * r, 8);  // -(u_i), i = r + 4 n
+      const uint32_t uip = __builtin_amdgcn_perm(static_cast<uint32_t>(ui), static_cast<uint32_t>(ui), 0x05040100u);
+      const uint32_t pr = pk_mad_i16_sat(uip, vjp, 0u);
+      uint32_t A[8];
+      unpack_pairs(par[n], A);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) A[p] = pk_mad_i16_sat(pr, wp[p], A[p]);
+      uint32_t cnz = 0, c16 = 0;
+      uint4 res = pack_pairs(A, cnz, c16);
+      if (__builtin_expect((c16 & 0xFF00FF00u) != 0, 0)) {  // rare: exact 32-bit form of this chunk (wrapped bytes + flag),
+        const int uv = ui * vj;                              // one dword at a time: the common path keeps 64 VGPRs
+        const uint32_t pd[4] = {par[n].x, par[n].y, par[n].z, par[n].w};
+        uint32_t rd[4];
+        int o32 = 0;
+        cnz = 0;
+#pragma unroll 1
+        for (int d = 0; d < 4; ++d) {
+          int e[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            e[t] = sbyte(pd[d], t) + uv * (sbyte(wq[d], t) - a.shift);
+            o32 |= e[t] + 128;
+          }
+          rd[d] = pack4(e[0], e[1], e[2], e[3]);
+          cnz |= rd[d];
+        }
+        res = uint4{rd[0], rd[1], rd[2], rd[3]};
+        ovf |= static_cast<uint32_t>(o32) & ~255u;
+      }
+      nz |= cnz;
+      const bool same = res.x == par[n].x && res.y == par[n].y && res.z == par[n].z && res.w == par[n].w;
+      par[n] = res;
+      if (!same) __builtin_amdgcn_raw_buffer_store_b128(u32x4{res.x, res.y, res.z, res.w}, srs, soff + 1024 * n, 0, 16);
+    }
+    const bool any_nz = __ballot(nz != 0) != 0;
+    if (lane == 0)
+      __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(any_nz ? 0 : 1), drs,
+                                           static_cast<int>(static_cast<int64_t>(k) * a.B + g), 0, 16);
+    if (__builtin_expect(ovf != 0, 0) && a.overflow) a.overflow[g] = 1;
+    if (a.progress) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(a.progress + g, static_cast<uint32_t>(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// =============================================================================================
 // terminal check / nnz, and reset
 // =============================================================================================
 
@@ -1402,8 +1495,14 @@ int tg_step_sparse_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_
 /* units (wavefronts) and games per unit of tg_step_stream_i8 for a batch of B games, or a negative TG_ERR_* */
 int tg_step_stream_layout(int64_t B, int S, int64_t* n_units, int* games_per_unit) {
   if (B < 0) return fail(TG_ERR_INVALID, "tg_step_stream_layout: B < 0");
-  if (S != 4) return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: S=%d (the streamed stepper is built for S=4)", S);
-  // every wavefront must be resident at once when the producer waits for the whole batch: 8 workgroups of 4
+  if (S != 4 && S != 16)
+    return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: S=%d (the streamed stepper is built for S=4 and S=16)", S);
+  if (S == 16) {  // one wavefront per game; 32 wavefronts per CU are resident at once (8192 games on 256 CUs)
+    if (n_units) *n_units = B;
+    if (games_per_unit) *games_per_unit = 1;
+    return TG_OK;
+  }
+  // S = 4: every wavefront must be resident at once when the producer waits for the whole batch: 8 workgroups of 4
   // wavefronts per CU at most, so larger batches give each wavefront more games (16 NG, NG <= 8)
   const int64_t cap = static_cast<int64_t>(device_cu_count()) * 32;
   int ng = 1;
@@ -1426,15 +1525,20 @@ int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8
   int64_t units = 0;
   int gpu_ = 0;
   if (int rc = tg_step_stream_layout(B, S, &units, &gpu_)) return rc;
-  if (!aligned16(state) || game_stride_bytes % 16 != 0 || !aligned4(actions) || B * game_stride_bytes > 0x7fffffffLL ||
-      static_cast<int64_t>(K) * B > 0x7fffffffLL || static_cast<unsigned>(shift + 127) > 254u)
-    return fail(TG_ERR_UNSUPPORTED, "%s: needs 16-byte aligned states, 4-byte aligned actions, B*stride and K*B < 2^31, |shift| <= 127", fn);
+  if (!aligned16(state) || game_stride_bytes % 16 != 0 || !(S == 16 ? aligned16(actions) : aligned4(actions)) ||
+      B * game_stride_bytes > 0x7fffffffLL || static_cast<int64_t>(K) * B > 0x7fffffffLL ||
+      static_cast<unsigned>(shift + 127) > 254u)
+    return fail(TG_ERR_UNSUPPORTED, "%s: needs 16-byte aligned states, aligned actions (4 bytes at S=4, 16 at S=16), B*stride and K*B < 2^31, |shift| <= 127", fn);
   if ((ready && (reinterpret_cast<uintptr_t>(ready) & 3)) || (progress && (reinterpret_cast<uintptr_t>(progress) & 3)))
     return fail(TG_ERR_INVALID, "%s: ready / progress must be 4-byte aligned", fn);
   tg::StreamArgs a{state, actions, done, overflow, ready, progress, status, B, game_stride_bytes, K, shift, 1u << 22};
   const unsigned grid = static_cast<unsigned>((units + 3) / 4);
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();
+  if (S == 16) {
+    hipLaunchKernelGGL(tg::s16_stream_kernel, dim3(grid), dim3(tg::kBlock), 0, st, a);
+    return check_launch(fn);
+  }
   switch (gpu_ / 16) {
     case 1: hipLaunchKernelGGL(tg::s4_stream_kernel<1>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
     case 2: hipLaunchKernelGGL(tg::s4_stream_kernel<2>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;

@@ -1115,18 +1115,19 @@ def test_bench_two_ranks_self_launched_on_one_gpu(tmp_path):
 
 
 # ------------------------------------------------------------------ tg_step_stream_i8 (K steps, one launch, actions arriving step by step)
-@pytest.mark.parametrize("B,K", [(1, 3), (16, 5), (70, 9), (1000, 14), (4099, 6)])
-def test_step_stream_equals_k_single_steps(B, K):
+@pytest.mark.parametrize("S,B,K", [(4, 1, 3), (4, 16, 5), (4, 70, 9), (4, 1000, 14), (4, 4099, 6),
+                                   (16, 1, 4), (16, 7, 9), (16, 130, 6), (16, 1030, 5)])
+def test_step_stream_equals_k_single_steps(S, B, K):
     """Every step of the streamed stepper equals tg_step_i8 / the oracle: state, done[k], sticky overflow; ragged
     batches, terminal games, an overflowing game, progress words; padded and packed layouts."""
-    rng = np.random.default_rng(B * 31 + K)
-    S = 4
+    rng = np.random.default_rng(B * 31 + K + S)
     st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
     ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(K, B, 3 * S)).astype(np.int8)
     st[::5] = O.action_to_tensor(ac[0, ::5]).astype(np.int8)              # these are done after step 0
     if B > 3:
         st[3] = 127
         ac[1, 3] = 0                                                       # factors -1: 127 - (-1) overflows at step 1
+        ac[2, 2] = rng.integers(-3, 6, size=3 * S)                         # wide factors (int16 path limits)
     want_done, want_ovf, cur = np.zeros((K, B), np.uint8), np.zeros(B, np.uint8), st.copy()
     for k in range(K):
         cur, d, o = O.step_i8(cur, ac[k])
@@ -1185,7 +1186,8 @@ def test_step_stream_waits_for_ready_words_and_times_out():
 
 
 def test_step_stream_refuses_what_it_does_not_implement():
-    t = ops.alloc_states(8, 16, DEV)
-    with pytest.raises(mat_mul_amd.TensorGameError, match="S=4"):
-        ops.step_stream(t, torch.ones((2, 8, 48), dtype=torch.int8, device=DEV))
+    t = ops.alloc_states(8, 9, DEV)
+    with pytest.raises(mat_mul_amd.TensorGameError, match="S=4 and S=16"):
+        ops.step_stream(t, torch.ones((2, 8, 27), dtype=torch.int8, device=DEV))
+    assert ops.step_stream_layout(8192, 16, DEV) == (8192, 1)
     assert ops.step_stream_layout(1 << 20, 4, DEV)[1] in (16, 32, 64, 128)
