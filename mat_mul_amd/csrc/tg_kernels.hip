@@ -860,7 +860,7 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
 // by the same wavefront in 32-bit.  Requires 16-byte aligned state and actions.
 // =============================================================================================
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void s16_step_kernel(ApplyArgs a) {
+__global__ __launch_bounds__(kBlock, 8) void s16_step_kernel(ApplyArgs a) {
   static_assert(MODE == STEP, "s16_step_kernel: single step only");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int64_t g = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave;
@@ -902,15 +902,25 @@ __global__ __launch_bounds__(kBlock) void s16_step_kernel(ApplyArgs a) {
     for (int p = 0; p < 8; ++p) A[p] = pk_mad_i16_sat(pr, wp[p], A[p]);
     uint32_t cnz = 0, c16 = 0;
     uint4 res = pack_pairs(A, cnz, c16);
-    if (__builtin_expect(wide_shift || (c16 & 0xFF00FF00u), 0)) {  // rare: exact 32-bit form of this chunk
-      const uint32_t wd[4] = {wq.x, wq.y, wq.z, wq.w};
+    if (__builtin_expect(wide_shift || (c16 & 0xFF00FF00u), 0)) {  // rare: exact 32-bit form of this chunk,
+      const uint32_t wd[4] = {wq.x, wq.y, wq.z, wq.w};              // one dword at a time (the common path keeps 64 VGPRs:
+      const uint32_t pd[4] = {par[n].x, par[n].y, par[n].z, par[n].w};  // 8 wavefronts per SIMD, cfg3 resident in one round)
       const int uv = ui * vj;
-      int acc[16], o32 = 0;
+      uint32_t rd[4];
+      int o32 = 0;
       cnz = 0;
-      unpack16(par[n], acc);
+#pragma unroll 1
+      for (int d = 0; d < 4; ++d) {
+        int e[4];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) acc[t] += uv * (sbyte(wd[t >> 2], t & 3) - a.shift);
-      res = pack16(acc, cnz, o32);
+        for (int t = 0; t < 4; ++t) {
+          e[t] = sbyte(pd[d], t) + uv * (sbyte(wd[d], t) - a.shift);
+          o32 |= e[t] + 128;
+        }
+        rd[d] = pack4(e[0], e[1], e[2], e[3]);
+        cnz |= rd[d];
+      }
+      res = uint4{rd[0], rd[1], rd[2], rd[3]};
       ovf |= static_cast<uint32_t>(o32) & ~255u;
     }
     nz |= cnz;
