@@ -91,6 +91,11 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
   asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {  // low 16 bits of a*b + c per half
   uint32_t d;
   asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));

@@ -8,6 +8,7 @@
 // rank-1 terms of the EMITTED tokens.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -36,6 +37,28 @@ __device__ __forceinline__ int draw_value(uint32_t d, const Dist& D) {
 #pragma unroll
   for (int t = 1; t < TG_MAX_VALUES; ++t) v = (idx == t) ? D.val[t] : v;
   return v;
+}
+
+// 16-byte chunk of a game from / to global memory; the game's last chunk holds only TAIL bytes
+template <int TAIL>
+__device__ __forceinline__ uint4 load_chunk16(const int8_t* p, bool tail) {
+  if (TAIL != 0 && tail) {
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < TAIL; ++t) w[t >> 2] |= static_cast<uint32_t>(static_cast<uint8_t>(p[t])) << (8 * (t & 3));
+    return uint4{w[0], w[1], w[2], w[3]};
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
+template <int TAIL>
+__device__ __forceinline__ void store_chunk16(int8_t* p, const uint4& q, bool tail) {
+  if (TAIL != 0 && tail) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int t = 0; t < TAIL; ++t) p[t] = static_cast<int8_t>(w[t >> 2] >> (8 * (t & 3)));
+    return;
+  }
+  *reinterpret_cast<uint4*>(p) = q;
 }
 
 constexpr uint32_t kStreamBasis = 0x80000000u;
@@ -403,16 +426,16 @@ __global__ __launch_bounds__(kBlock) void sample_basis_mfma_kernel(int8_t* P, in
 // CB threads per game.  At S = 25 the int32 tensor in LDS (65 KB) allows only two workgroups per CU, and two
 // 256-thread workgroups are two wavefronts per SIMD -- nothing to hide the LDS latency of the fibre loop behind:
 // 1024 threads there (686 -> 393 us at B = 4096), 256 for the small tensors (S^2 fibres <= 256).
+// One game by the CB threads of the calling workgroup; X = the dynamic LDS (see tg_change_basis_i8 for its size).
 template <int ST, int CB>
-__global__ __launch_bounds__(CB) void change_basis_kernel(const int8_t* in, const int32_t* basis, int8_t* out,
-                                                              uint8_t* overflow, int64_t B, int Srt, int64_t stride) {
-  extern __shared__ __attribute__((aligned(16))) int X[];
+__device__ __forceinline__ void change_basis_game(const int8_t* in, const int32_t* basis, int8_t* out, uint8_t* overflow,
+                                                  int64_t b, int Srt, int64_t stride, int* X) {
   const int S = ST ? ST : Srt;
   const int P = S + 1, S2 = S * S, N = S2 * S;
   constexpr int SP = ((ST ? ST : TG_MAX_S) + 3) & ~3;  // fibre length padded to whole ds_read_b128
   const int MP = (S + 3) & ~3;
   int* const Ms = X + ((S2 * P + 3) & ~3);             // this mode's matrix, rows of MP ints
-  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+  {
     const int8_t* src = in + b * stride;
     for (int e = threadIdx.x; e < N; e += CB) {
       const int i = e / S2, r = e - i * S2, j = r / S, k = r - j * S;
@@ -477,6 +500,233 @@ __global__ __launch_bounds__(CB) void change_basis_kernel(const int8_t* in, cons
     }
     ovf = __syncthreads_or(ovf);
     if (threadIdx.x == 0 && overflow && ovf) overflow[b] = 1;
+  }
+}
+
+template <int ST, int CB>
+__global__ __launch_bounds__(CB) void change_basis_kernel(const int8_t* in, const int32_t* basis, int8_t* out,
+                                                              uint8_t* overflow, int64_t B, int Srt, int64_t stride) {
+  extern __shared__ __attribute__((aligned(16))) int X[];
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) change_basis_game<ST, CB>(in, basis, out, overflow, b, Srt, stride, X);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same three mode products on the int8 matrix cores (S = 9, 16, 25; round 2).  Per game and mode the product is a
+// GEMM whose contracted index has at most 32 values: ONE v_mfma_i32_32x32x32_i8 per 32 rows and operand plane.
+//   stage 1 (mode 3):  Y1[(i,j)][c] = sum_k X[(i,j)][k] C[c][k]   tensor rows straight from the state image (k is
+//                      contiguous in memory), B operand = rows of C.  |Y1| <= 127 rc may need 16 bits: stored as two
+//                      byte planes, lo = low byte (signed), hi = (y + 128) >> 8, in the layout [c][i][j] (j fastest,
+//                      32-byte rows) -- the MFMA result has four consecutive rows per register group, so four
+//                      consecutive j leave as ONE dword per plane.
+//   stage 2 (mode 2):  Y2[(c,i)][b] = sum_j Y1[(c,i)][j] B[b][j]   one tile per c (rows i): two MFMAs (lo, hi planes),
+//                      x = (hi << 8) + lo; written IN PLACE over the tile's own block as [c][b][i] (i fastest).
+//   stage 3 (mode 1):  T'[a][b][c] = sum_i Y2[(c,b)][i] A[a][i]   one tile per c (rows b); int32 results, range
+//                      checked, low bytes into the output image.
+// Exact while every basis entry fits int8 and the intermediates fit 16 bits: max|X| rc <= 32767 and max|X| rc rb <= 32767
+// with rc, rb the largest absolute row sums of C and B (checked per game from the data); any other game is done by the
+// vector form above (change_basis_game) inside the same launch.
+// ---------------------------------------------------------------------------------------------------------------
+template <int S>
+struct CBGeo {
+  static constexpr int N = S * S * S, S2 = S * S;
+  static constexpr int NCHUNK = (N + 15) / 16, TAIL = N % 16, IMG = NCHUNK * 16;
+  static constexpr int CP = S * 32 + 16;                   // pitch of a c-block: + 16 B spreads the lanes' (= c's) dword writes over 8 banks
+  static constexpr int PLANE = S * CP;                     // [c][row][32] bytes
+  static constexpr int MAT = 3 * 32 * 32;                  // three int8 matrices, 32 x 32, zero padded
+  static constexpr int FAST_BYTES = IMG + 48 + 2 * PLANE + MAT + 64;
+  static constexpr int SLOW_BYTES = (((S2 * (S + 1) + 3) & ~3) + S * ((S + 3) & ~3) + 32) * 4;
+  static constexpr int LDS_BYTES = FAST_BYTES > SLOW_BYTES ? FAST_BYTES : SLOW_BYTES;
+};
+
+// NW wavefronts per workgroup share the game's LDS: the kernel holds one or two workgroups per CU (the vector fallback's
+// int32 tensor decides the LDS size), so the wavefronts that hide each other's MFMA / LDS latency must come from the
+// workgroup itself.
+template <int S, int NW>
+__global__ __launch_bounds__(64 * NW) void change_basis_mfma_kernel(const int8_t* in, const int32_t* basis, int8_t* out,
+                                                                    uint8_t* overflow, int64_t B, int64_t stride) {
+  using G = CBGeo<S>;
+  constexpr int kThreads = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) int X[];
+  uint8_t* const smem = reinterpret_cast<uint8_t*>(X);
+  uint8_t* const img = smem;                                    // the state image, later the output image
+  int8_t* const Ylo = reinterpret_cast<int8_t*>(smem + G::IMG + 48);
+  int8_t* const Yhi = Ylo + G::PLANE;
+  int8_t* const M8 = Yhi + G::PLANE;                            // [mode][row][32]
+  int* const red = reinterpret_cast<int*>(M8 + G::MAT);         // [0] not eligible, [1..3] row-sum maxima, [4] overflow, [5] max |X0|
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  constexpr int JP = (S + 3) & ~3;                              // stage 1: rows per i, padded to a multiple of four
+  constexpr int NT1 = (S * JP + 31) / 32;                       // stage 1: tiles of 32 rows n' = i JP + j
+
+  for (int64_t g = blockIdx.x; g < B; g += gridDim.x) {
+    // ---- 0. state image, int8 matrices (zero padded), eligibility ----
+    if (tid < 8) red[tid] = 0;
+    for (int e = tid; e < G::MAT / 4; e += kThreads) reinterpret_cast<uint32_t*>(M8)[e] = 0;
+    {
+      const int8_t* src = in + g * stride;
+      uint32_t mxe = 0, mxo = 0;  // running max of |x| over even / odd bytes (two 16-bit lanes each)
+      for (int c = tid; c < G::NCHUNK; c += kThreads) {
+        const uint4 q = load_chunk16<G::TAIL>(src + 16 * c, c == G::NCHUNK - 1);
+        *reinterpret_cast<uint4*>(img + 16 * c) = q;
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t s1 = (w[t] >> 7) & 0x01010101u, ax = (w[t] ^ (s1 * 0xFFu)) + s1;  // |x| per byte (128 for -128)
+          mxe = pk_max_u16(mxe, ax & 0x00FF00FFu);
+          mxo = pk_max_u16(mxo, (ax >> 8) & 0x00FF00FFu);
+        }
+      }
+      const uint32_t m2 = pk_max_u16(mxe, mxo);
+      int mine = static_cast<int>(max(m2 & 0xFFFFu, m2 >> 16));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mine = max(mine, __shfl_xor(mine, o));  // one LDS atomic per wavefront, not per lane
+      if (lane == 0 && mine) atomicMax(&red[5], mine);
+    }
+    __syncthreads();
+    {
+      const int32_t* Mg = basis + g * 3 * G::S2;
+      int bad = 0;
+      for (int e = tid; e < 3 * G::S2; e += kThreads) {
+        const int m = e / G::S2, r = e - m * G::S2, a = r / S, t = r - a * S;
+        const int v = Mg[e];
+        bad |= (v > 127) | (v < -127);
+        M8[(m * 32 + a) * 32 + t] = static_cast<int8_t>(v);
+      }
+      if (bad) red[0] = 1;
+    }
+    __syncthreads();
+    if (tid < 3 * S) {  // row sums of |M| (one row per thread), maxima per mode
+      const int m = tid / S, a = tid - m * S;
+      int rs = 0;
+      for (int t = 0; t < S; ++t) {
+        const int v = M8[(m * 32 + a) * 32 + t];
+        rs += v < 0 ? -v : v;
+      }
+      atomicMax(&red[1 + m], rs);
+    }
+    __syncthreads();
+    const int rb = red[2], rc = red[3], mx0 = red[5];  // (the last stage's sums are int32: no condition on A's rows)
+    // |Y1| <= mx0 rc and |Y2| <= mx0 rc rb must fit the two byte planes (16 bits); workgroup-uniform
+    const bool eligible = red[0] == 0 && static_cast<int64_t>(mx0) * rc <= 32767 && static_cast<int64_t>(mx0) * rc * rb <= 32767;
+    if (!eligible) {
+      __syncthreads();
+      change_basis_game<S, kThreads>(in, basis, out, overflow, g, S, stride, X);
+      __syncthreads();
+      continue;
+    }
+    // B-operand fragments of the three stages: row `col` of the mode's matrix, bytes 16h .. 16h+15 (zero beyond S)
+    const bt_v4i fC = *reinterpret_cast<const bt_v4i*>(M8 + (2 * 32 + col) * 32 + 16 * h);
+    const bt_v4i fB = *reinterpret_cast<const bt_v4i*>(M8 + (1 * 32 + col) * 32 + 16 * h);
+    const bt_v4i fA = *reinterpret_cast<const bt_v4i*>(M8 + (0 * 32 + col) * 32 + 16 * h);
+
+    // two byte planes of four consecutive results -> one dword each
+    auto split4 = [&](const bt_v16i& acc, int q, uint32_t& lo, uint32_t& hi) {
+      lo = pack4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+      hi = pack4((acc[4 * q] + 128) >> 8, (acc[4 * q + 1] + 128) >> 8, (acc[4 * q + 2] + 128) >> 8, (acc[4 * q + 3] + 128) >> 8);
+    };
+
+    // ---- 1. contract k with C: rows (i,j) from the image, results to planes [c][i][j] ----
+    // The row space is padded to JP = ceil4(S) rows per i (n' = i JP + j): a register group's four consecutive rows then
+    // share i and start at a multiple of four, so the four results leave as ONE ALIGNED dword per plane (unaligned LDS
+    // dwords stall on gfx950); the JP - S padding rows of every i shadow a valid row and land in the row's padding bytes.
+    for (int t1 = wave; t1 < NT1; t1 += NW) {
+      const int n = 32 * t1 + col;
+      const int ni = n / JP, nj = n - ni * JP;
+      const int vi = ni < S ? ni : S - 1, vj = nj < S ? nj : S - 1;  // padding rows shadow a valid one
+      const int off = (vi * S + vj) * S + 16 * h;          // 16 bytes of the row (bytes k >= S meet zero rows of C)
+      const uint32_t* p4 = reinterpret_cast<const uint32_t*>(img + (off & ~3));
+      uint32_t d[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) d[t] = p4[t];
+      bt_v4i fx;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fx[t] = static_cast<int>(__builtin_amdgcn_alignbyte(d[t + 1], d[t], static_cast<uint32_t>(off & 3)));
+      bt_v16i acc;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[t] = 0;
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx, fC, acc, 0, 0, 0);  // D[row n'][col c]
+      if (col < S) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n0 = 32 * t1 + 8 * q + 4 * h;        // rows n0 .. n0+3 of this register group: one i, j0 % 4 == 0
+          const int i0 = n0 / JP, j0 = n0 - i0 * JP;
+          if (i0 < S) {
+            uint32_t lo, hi;
+            split4(acc, q, lo, hi);
+            const int o = col * G::CP + i0 * 32 + j0;
+            *reinterpret_cast<uint32_t*>(Ylo + o) = lo;
+            *reinterpret_cast<uint32_t*>(Yhi + o) = hi;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // (bytes j >= S of a plane row hold shadows or stale bytes: they meet the zero rows k >= S of the B operand)
+
+    // ---- 2. contract j with B: one tile per c (rows i), in place -> [c][b][i] ----
+    for (int c = wave; c < S; c += NW) {
+      const int row = col < S ? col : S - 1;             // rows i >= S shadow the last one; never stored
+      const bt_v4i xl = *reinterpret_cast<const bt_v4i*>(Ylo + c * G::CP + row * 32 + 16 * h);
+      const bt_v4i xh = *reinterpret_cast<const bt_v4i*>(Yhi + c * G::CP + row * 32 + 16 * h);
+      bt_v16i al, ah;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) al[t] = ah[t] = 0;
+      al = __builtin_amdgcn_mfma_i32_32x32x32_i8(xl, fB, al, 0, 0, 0);  // D[row i][col b]
+      ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(xh, fB, ah, 0, 0, 0);
+      // low planes are signed bytes and high planes signed: y = 256 hi + lo
+#pragma unroll
+      for (int t = 0; t < 16; ++t) al[t] += ah[t] << 8;
+      if (col < S) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i0 = 8 * q + 4 * h;
+          if (8 * q < S && i0 < S) {                     // (rows i0+t >= S: zero results, written into the row's padding)
+            uint32_t lo, hi;
+            split4(al, q, lo, hi);
+            const int o = c * G::CP + col * 32 + i0;
+            *reinterpret_cast<uint32_t*>(Ylo + o) = lo;
+            *reinterpret_cast<uint32_t*>(Yhi + o) = hi;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- 3. contract i with A: one tile per c; the matrix is the A operand (rows a), the tile's rows (c,b) the B
+    // operand, so the result has b on the lane and a in the registers: T'[a][b][c] goes to the output image with a lane
+    // stride of S bytes (lane = a would stride S^2: every lane on one bank at S = 16) ----
+    int hi3 = 0, lo3 = 0;
+    for (int c = wave; c < S; c += NW) {
+      const int row = col < S ? col : S - 1;
+      const bt_v4i xl = *reinterpret_cast<const bt_v4i*>(Ylo + c * G::CP + row * 32 + 16 * h);
+      const bt_v4i xh = *reinterpret_cast<const bt_v4i*>(Yhi + c * G::CP + row * 32 + 16 * h);
+      bt_v16i al, ah;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) al[t] = ah[t] = 0;
+      al = __builtin_amdgcn_mfma_i32_32x32x32_i8(fA, xl, al, 0, 0, 0);  // D[row a][col b]
+      ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(fA, xh, ah, 0, 0, 0);
+      if (col < S) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int a = (t & 3) + 8 * (t >> 2) + 4 * h;
+          if ((t & 3) + 8 * (t >> 2) < S && a < S) {
+            const int v = al[t] + (ah[t] << 8);
+            hi3 = max(hi3, v);
+            lo3 = min(lo3, v);
+            img[(a * S + col) * S + c] = static_cast<uint8_t>(v);
+          }
+        }
+      }
+    }
+    if (__ballot((hi3 > 127) | (lo3 < -128)) != 0 && lane == 0) red[4] = 1;
+    __syncthreads();
+    {
+      int8_t* dst = out + g * stride;
+      for (int c = tid; c < G::NCHUNK; c += kThreads)
+        store_chunk16<G::TAIL>(dst + 16 * c, *reinterpret_cast<const uint4*>(img + 16 * c), c == G::NCHUNK - 1);
+      if (tid == 0 && overflow && red[4]) overflow[g] = 1;
+    }
+    __syncthreads();
   }
 }
 
@@ -649,11 +899,43 @@ int tg_change_basis_i8(const int8_t* state_in, const int32_t* basis, int8_t* sta
   if (B && state_in && state_in == state_out) return tg_internal_fail(TG_ERR_INVALID, "%s: in-place is not supported", fn);
   if (B == 0) return TG_OK;
   if (!state_in || !basis || !state_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // S = 9 / 16 / 25 on aligned layouts: the matrix-core kernel (games it cannot do exactly take the vector form inside it)
+  if (!TG_SWITCH("TG_NO_MFMA") && (S == 9 || S == 16 || S == 25) && (reinterpret_cast<uintptr_t>(state_in) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(state_out) & 15) == 0 && game_stride_bytes % 16 == 0) {
+    static std::atomic<unsigned> attr_set[3][64];  // per (S, device): the > 64 KiB dynamic LDS opt-in, once
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const dim3 mgrid(grid_for(B > 4LL * cus ? 4LL * cus : B));
+#define TG_CBM(S_, IDX_, NW_)                                                                                  \
+  do {                                                                                                         \
+    constexpr int ldsb = tg::CBGeo<S_>::LDS_BYTES;                                                             \
+    if (ldsb > 64 * 1024 && !attr_set[IDX_][dev].load(std::memory_order_relaxed)) {                            \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tg::change_basis_mfma_kernel<S_, NW_>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);                    \
+      if (e != hipSuccess) return tg_internal_fail(TG_ERR_HIP, "%s: %s", fn, hipGetErrorString(e));            \
+      attr_set[IDX_][dev].store(1, std::memory_order_relaxed);                                                 \
+    }                                                                                                          \
+    (void)hipGetLastError();                                                                                   \
+    hipLaunchKernelGGL((tg::change_basis_mfma_kernel<S_, NW_>), mgrid, dim3(64 * NW_), ldsb, st, state_in, basis, state_out, \
+                       overflow, B, game_stride_bytes);                                                        \
+    return launched(fn);                                                                                       \
+  } while (0)
+    if (S == 9) TG_CBM(9, 0, 4);
+    if (S == 16) TG_CBM(16, 1, 4);
+#ifdef TG_AB_SWITCHES
+    if (getenv("TG_CB_NW") && atoi(getenv("TG_CB_NW")) == 4) TG_CBM(25, 2, 4);
+    if (getenv("TG_CB_NW") && atoi(getenv("TG_CB_NW")) == 16) TG_CBM(25, 2, 16);
+#endif
+    TG_CBM(25, 2, 8);
+#undef TG_CBM
+  }
   // int32 tensor with rows padded to S+1, then one mode's matrix with rows padded to whole 16-byte reads (+ slack
   // for the run-time-S kernel, whose unrolled row loop may read past the last row into zero-weighted entries)
   const size_t lds = ((static_cast<size_t>(S) * S * (S + 1) + 3) / 4 * 4 + static_cast<size_t>(S) * ((S + 3) / 4 * 4) + 32) * sizeof(int);
   if (lds > 160 * 1024) return tg_internal_fail(TG_ERR_UNSUPPORTED, "%s: S=%d needs %zu B of LDS", fn, S, lds);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(grid_for(B));
 #define TG_CB(ST, CB)                                                                                  \
   do {                                                                                                 \

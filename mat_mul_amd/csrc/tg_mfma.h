@@ -421,6 +421,9 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
 #pragma unroll
   for (int d = 0; d < 4; ++d) idp[d] = col < S ? ida[d] : 0;
 
+  if (tid < 8) red[tid] = 0;
+  int orpar = 0;
+  __syncthreads();
   for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
     // ---- 1. factors (u negated: the products are subtracted), transposed into LDS; X0 into the image ----
     const __amdgpu_buffer_rsrc_t tok = __builtin_amdgcn_make_buffer_rsrc(
@@ -456,8 +459,15 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       for (int c = tid; c < G::NCHUNK; c += kBlock)
         *reinterpret_cast<uint4*>(img + 16 * c) = load_chunk<G::TAIL>(src + 16 * c, c == G::NCHUNK - 1);
     }
-    if (tid < 8) red[tid] = 0;
-    if (__syncthreads_or(big)) {  // factors beyond the byte products: the lattice kernels take this game
+    if (tid < 4) red[tid] = 0;
+    // workgroup OR of `big` with ONE barrier (HIP's __syncthreads_or costs three): red[4 + parity] was cleared during
+    // the previous game, is OR-ed here, read after the barrier; the other word is cleared for the next game
+    if (big) atomicOr(reinterpret_cast<unsigned*>(&red[4 + orpar]), 1u);
+    __syncthreads();
+    const bool anybig = red[4 + orpar] != 0;
+    if (tid == 0) red[4 + (orpar ^ 1)] = 0;
+    orpar ^= 1;
+    if (anybig) {  // factors beyond the byte products: the lattice kernels take this game
       if (tid == 0) {
         a.done_step[g] = kNeedsExact;
         atomicAdd(&g_many_handovers, 1ull);

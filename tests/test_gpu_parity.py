@@ -1191,3 +1191,30 @@ def test_step_stream_refuses_what_it_does_not_implement():
         ops.step_stream(t, torch.ones((2, 8, 27), dtype=torch.int8, device=DEV))
     assert ops.step_stream_layout(8192, 16, DEV) == (8192, 1)
     assert ops.step_stream_layout(1 << 20, 4, DEV)[1] in (16, 32, 64, 128)
+
+
+# ------------------------------------------------------------------ change of basis on the matrix cores
+@pytest.mark.parametrize("S,B", [(9, 37), (16, 21), (25, 9)])
+def test_change_basis_matrix_core_kernel_and_its_fallbacks(S, B):
+    """tg_change_basis_i8 (A12; parity unpinned: the oracle is the paper-level einsum): sparse unimodular bases and their
+    exact inverses, dense {-1,0,1} matrices, entries at +-127, entries beyond int8 (vector form inside the same launch),
+    targets that overflow int8 (wrap + flag), the state -128, identity."""
+    rng = np.random.default_rng(S * 7 + B)
+    thr = O.categorical_thresholds((0.15, 0.7, 0.15))
+    _, tgt, _ = O.gen_demos_i8(B, S, 20, thr, (-1, 0, 1), 1, seed=S)
+    Pm, L, U = O.sample_basis(B, S, O.categorical_thresholds((0.03, 0.94, 0.03)), (-1, 0, 1), seed=S + 1)
+    bases = {"sparse unimodular": Pm, "its inverse": O.unimodular_inverse(L, U),
+             "dense ternary": rng.integers(-1, 2, size=(B, 3, S, S)),
+             "entries up to 127": np.where(rng.random((B, 3, S, S)) < 0.04, rng.integers(-127, 128, size=(B, 3, S, S)), 0) + np.eye(S, dtype=np.int64),
+             "entries beyond int8": np.where(rng.random((B, 3, S, S)) < 0.03, rng.integers(-1000, 1001, size=(B, 3, S, S)), 0) + np.eye(S, dtype=np.int64),
+             "identity": np.broadcast_to(np.eye(S, dtype=np.int64), (B, 3, S, S)).copy()}
+    states = {"demo targets": tgt, "full range": rng.integers(-128, 128, size=(B, S, S, S)).astype(np.int8)}
+    for sname, st in states.items():
+        for bname, M in bases.items():
+            want, want_ovf = O.change_basis_i8(st, M)
+            ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+            got = ops.change_basis(padded(st), dev(M.astype(np.int32)), overflow=ovf)
+            assert np.array_equal(host(got), want), (S, sname, bname)
+            assert np.array_equal(host(ovf), want_ovf), (S, sname, bname)
+    want, want_ovf = O.change_basis_i8(tgt, Pm)
+    assert (want_ovf == 0).sum() > 0                        # the sparse basis keeps some targets in range
