@@ -76,16 +76,28 @@ __device__ __forceinline__ bool flagged_or_all(const ApplyArgs& a, int64_t b) {
   return true;
 }
 
+// Workgroup OR of two flag bits with ONE barrier (HIP's __syncthreads_or costs three and an LDS atomic round trip): every
+// wavefront stores its ballots into its own LDS word -- nothing to zero first -- and after the barrier everybody reads
+// the kBlock / 64 words.  `slots`: 16 bytes of LDS, 16-byte aligned, not written again before the next barrier.
+__device__ __forceinline__ uint32_t block_or2(uint32_t v, uint32_t* slots) {
+  static_assert(kBlock == 256, "four wavefront slots");
+  const uint32_t w = (__ballot((v & 1u) != 0) ? 1u : 0u) | (__ballot((v & 2u) != 0) ? 2u : 0u);
+  if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = w;
+  __syncthreads();
+  const uint4 q = *reinterpret_cast<const uint4*>(slots);
+  return q.x | q.y | q.z | q.w;
+}
+
 template <int TS>
 __device__ __forceinline__ bool factors_too_large(const int8_t* tok, int nact, int at, int tok_per_action,
-                                                  int8_t* raw, int lt, int shift, int flim, int& head0) {
+                                                  int8_t* raw, int lt, int shift, int flim, int& head0, uint32_t* slots) {
   int big, hd;
   if (nact <= at) {
     big = load_tokens_checked<TS>(tok, nact * tok_per_action, raw, lt, shift, flim, head0);
   } else {
     big = load_tokens_checked<TS>(tok, nact * tok_per_action, nullptr, lt, shift, flim, hd);
   }
-  return __syncthreads_or(big) != 0;
+  return block_or2(big ? 1u : 0u, slots) != 0;  // (the barrier also completes the raw tokens in LDS)
 }
 
 template <int S, int TS>
@@ -182,7 +194,7 @@ constexpr int packed_lds_bytes(int at) {
   const int tables = G::GPB * at * G::FSTRIDE * 2;
   const int raw = G::GPB * ((at * 3 * S + 8 + 3) & ~3);
   const int nflag = MODE == MANY ? TG_MAX_ACTIONS + 16 : cmax(4, 3 * G::GPB * at);  // MANY: + recompute byte per team
-  return tables + raw + ((nflag + 3) & ~3);
+  return ((tables + raw + ((nflag + 3) & ~3) + 15) & ~15) + 32;  // + two 16-byte slot arrays of block_or2
 }
 
 template <int S, int TS, int MODE>
@@ -193,6 +205,8 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
   const int raw_stride = (at * 3 * S + 8 + 3) & ~3;  // bytes of raw tokens per team
   int8_t* const raw_all = reinterpret_cast<int8_t*>(lds + G::GPB * at * G::FSTRIDE);
   uint8_t* const flags = reinterpret_cast<uint8_t*>(raw_all + G::GPB * raw_stride);
+  // the last 32 bytes of the dynamic LDS (16-byte aligned): two slot arrays for block_or2
+  uint32_t* const or_slots = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(lds) + packed_lds_bytes<S, TS, MODE>(at) - 32);
 
   const int tid = threadIdx.x;
   const int team = tid / TS, lt = tid % TS;
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
   };
 
   int head0 = 0;
-  if (factors_too_large<TS>(tok, a.nact, at, 3 * S, raw, lt, a.shift, flim, head0)) {
+  if (factors_too_large<TS>(tok, a.nact, at, 3 * S, raw, lt, a.shift, flim, head0, or_slots)) {
     // exact byte-wise form, one game at a time (rare; speed is irrelevant)
     note_fallback();
     for (int t = 0; t < G::GPB; ++t) {
@@ -294,8 +308,8 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
     if (!loaded) {
       __syncthreads();  // previous tile's tables and raw bytes are no longer read
       load_raw(a0, na, head);
-    }
-    __syncthreads();
+      __syncthreads();
+    }  // (loaded: the barrier inside factors_too_large has already completed the raw tokens)
     for (int k = 0; k < na; ++k) {
       const int8_t* t = raw + head + k * (3 * S);
 #pragma unroll
@@ -375,8 +389,9 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
     }
     bool any_nz, any_ovf;
     if constexpr (TS == 256) {
-      any_nz = __syncthreads_or(nz != 0);
-      any_ovf = __syncthreads_or((ovf & 0xFF00FF00u) != 0);
+      const uint32_t both = block_or2((nz != 0 ? 1u : 0u) | ((ovf & 0xFF00FF00u) != 0 ? 2u : 0u), or_slots + 4);
+      any_nz = (both & 1u) != 0;
+      any_ovf = (both & 2u) != 0;
     } else {
       any_nz = team_any<TS>(nz != 0);
       any_ovf = team_any<TS>((ovf & 0xFF00FF00u) != 0);

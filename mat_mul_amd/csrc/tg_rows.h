@@ -43,7 +43,7 @@ constexpr int rows_lds_bytes(int at) {
   const int state = G::GPB * G::STATE_BYTES;
   const int raw = G::GPB * ((at * 3 * S + 8 + 15) & ~15);
   const int nflag = (MODE == MANY ? TG_MAX_ACTIONS : 0) + 16;  // + one "recompute" byte per team
-  return tables + state + raw + nflag;
+  return ((tables + state + raw + nflag + 15) & ~15) + 16;     // + the slot array of block_or2
 }
 
 template <int S, int TS, int MODE>
@@ -79,7 +79,8 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ApplyArgs a, int flim, int
   };
 
   int head0 = 0;
-  if (factors_too_large<TS>(tok, a.nact, at, 3 * S, raw, lt, a.shift, flim, head0)) {
+  if (factors_too_large<TS>(tok, a.nact, at, 3 * S, raw, lt, a.shift, flim, head0,
+                            reinterpret_cast<uint32_t*>(smem + rows_lds_bytes<S, TS, MODE>(at) - 16))) {
     note_fallback();
     for (int t = 0; t < G::GPB; ++t) {
       const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
