@@ -1185,6 +1185,43 @@ def test_step_stream_waits_for_ready_words_and_times_out():
     assert int(status[0]) == 1 and np.array_equal(host(t2), two)
 
 
+@pytest.mark.parametrize("S,B", [(4, 700), (16, 90)])
+def test_step_stream_hand_off_is_visible_while_the_kernel_runs(S, B):
+    """The publish protocol end to end: a consumer (this test, on another stream) waits for progress[u] >= k on every
+    unit, READS the state while the stepper is still resident -- it must already equal the oracle's state after k steps
+    (write-through stores drained before the progress word) -- and only then releases action block k."""
+    rng = np.random.default_rng(S + B)
+    K = 5
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(K, B, 3 * S)).astype(np.int8)
+    t = padded(st)
+    acd = dev(ac)
+    ready = torch.zeros(K, dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    n_units, _ = ops.step_stream_layout(B, S, DEV)
+    prog = torch.zeros(n_units, dtype=torch.int32, device=DEV)
+    done = torch.zeros((K, B), dtype=torch.uint8, device=DEV)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ops.step_stream(t, acd, done=done, ready=ready, progress=prog, status=status)
+    import time
+    cur = st.copy()
+    for k in range(K):
+        t0 = time.time()
+        while int(prog.min()) < k:                                   # (a tiny kernel + copy on the default stream)
+            assert time.time() - t0 < 20, "the stepper made no progress"
+        seen = host(t.clone())                                        # read while the stepper is resident
+        assert np.array_equal(seen, cur), (S, k)
+        if k:
+            assert np.array_equal(host(done[k - 1].clone()), want_done), (S, k)
+        cur, want_done, _ = O.step_i8(cur, ac[k])
+        ready[k:k + 1].fill_(1)
+        torch.cuda.current_stream().synchronize()
+    side.synchronize()
+    assert int(status[0]) == 0 and np.array_equal(host(t), cur) and bool((prog == K).all())
+
+
 def test_step_stream_refuses_what_it_does_not_implement():
     t = ops.alloc_states(8, 9, DEV)
     with pytest.raises(mat_mul_amd.TensorGameError, match="S=4 and S=16"):
