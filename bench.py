@@ -53,8 +53,14 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 INFINITY_CACHE_BYTES = 256 << 20
-STEP_KERNEL = {4: "tg::s4_kernel<0>", 16: "tg::s16_step_kernel<0>", 9: "tg::packed_kernel<9, 16, 0>",
-               25: "tg::packed_kernel<25, 256, 0>"}
+STEP_KERNEL = {4: "tg::s4_kernel<0>", 9: "tg::packed_kernel<9, 16, 0>", 25: "tg::s25_step_kernel"}
+
+
+def step_kernel_name(S: int, B: int) -> str:
+    """The kernel tg_step_i8 launches for aligned int8 states (tg_kernels.hip, apply_launch)."""
+    if S == 16:  # whole-line stores from 96 MiB of states on
+        return "tg::s16_step_kernel<0, true>" if B * 4096 >= (96 << 20) else "tg::s16_step_kernel<0, false>"
+    return STEP_KERNEL.get(S, "tg::slow_kernel<0>")
 
 
 def bytes_step(S: int) -> int:
@@ -120,7 +126,7 @@ def needed_bytes_per_launch(B, S, sched, inplace=True):
     """Bytes one launch must move: read state + tokens, write `done`, write the state -- except that in place the
     S>=9 kernels do not store 16-byte chunks the action leaves unchanged (the S=4 kernel always stores)."""
     alg = B * bytes_step(S)
-    if S == 4 or not inplace or S not in STEP_KERNEL:
+    if S == 4 or not inplace or S not in (9, 16, 25):  # (the sizes with a store-skipping in-place kernel)
         return alg
     return B * (S ** 3 + 3 * S + 1) + 16.0 * changed_chunks_per_launch(S, sched)
 
@@ -314,7 +320,7 @@ def roofline(B, S, K, event_ms_samples, needed_bytes=None, copy=None, footprint=
     per_launch_s = statistics.median(event_ms_samples) * 1e-3 / K
     alg = B * bytes_step(S)
     need = alg if needed_bytes is None else min(float(needed_bytes), float(alg))
-    kernel = STEP_KERNEL.get(S, "tg::slow_kernel<0>")
+    kernel = step_kernel_name(S, B)
     traffic, tround = measured_traffic(B, S, kernel)
     footprint = footprint if footprint is not None else B * (-(-S ** 3 // 16) * 16)
     out = {"bound": "hbm", "achieved": round(need / per_launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

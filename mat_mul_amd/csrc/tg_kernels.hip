@@ -858,75 +858,168 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
 // (The staged packed_kernel needs three barriers; at S = 16 the step is bound by that chain per
 // wavefront, not by bandwidth -- see DESIGN.md.)  Factors beyond the 16-bit path's range are handled
 // by the same wavefront in 32-bit.  Requires 16-byte aligned state and actions.
+//
+// Arithmetic only where the action acts.  A row (i, j) changes only when u_i v_j != 0 -- 9 % of the rows under the
+// reference's factor distribution -- but a wave instruction covers four values of i and all sixteen j, so skipping
+// per instruction almost never fires, and the unpack / multiply-add / pack / range test of all four chunks was 45 % of
+// the kernel (measured by ablation: 4.0 us without it at BASELINE config 3, 6.6 with; 83 us against 148 at 131 072
+// games, where 83 us is also what a bare read of the same bytes takes).  So the rows that change are COMPACTED:
+// each lane appends its candidate chunks (16 bytes + chunk index + the product -u_i v_j) to a 64-entry queue of its
+// wavefront in LDS (slot = running count + mbcnt of the ballot), and one dense pass -- lane k takes entry k --
+// does the arithmetic and stores the result straight to the game.  Unchanged chunks only feed the zero test.
+// A game with more than 64 candidate rows (dense factors) takes the direct form: all four chunks of every lane.
 // =============================================================================================
-template <int MODE>
-__global__ __launch_bounds__(kBlock, 8) void s16_step_kernel(ApplyArgs a) {
+// one chunk: x - (-uv) ... i.e. x + uvn * w, uvn = -u_i v_j; saturating int16 form, 32-bit redo when the range test fails
+__device__ __forceinline__ uint4 s16_chunk(const uint4& x, int uvn, const uint32_t (&wp)[8], const uint4& wq, int shift,
+                                           bool wide_shift, uint32_t& cnz, uint32_t& ovf) {
+  // Saturating int16 form, as in s4_step_slice: with |factor| <= 255 (int8 tokens, |shift| <= 127) the clamped u*v and
+  // (u v) w + x are formed exactly or saturate, so everything the 16-bit form cannot represent ends outside int8 --
+  // exactly the results that overflow.  No check of the factors; a chunk whose range test fails is redone in 32-bit by
+  // its lane (wrapped bytes + flag).
+  const int cl = max(-32767, min(32767, uvn));
+  const uint32_t pr = __builtin_amdgcn_perm(static_cast<uint32_t>(cl), static_cast<uint32_t>(cl), 0x05040100u);
+  uint32_t A[8];
+  unpack_pairs(x, A);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) A[p] = pk_mad_i16_sat(pr, wp[p], A[p]);
+  uint32_t c16 = 0;
+  cnz = 0;
+  uint4 res = pack_pairs(A, cnz, c16);
+  if (__builtin_expect(wide_shift || (c16 & 0xFF00FF00u), 0)) {  // rare: exact 32-bit form of this chunk,
+    const uint32_t wd[4] = {wq.x, wq.y, wq.z, wq.w};              // one dword at a time (the common path keeps <= 64 VGPRs:
+    const uint32_t pd[4] = {x.x, x.y, x.z, x.w};                  // 8 wavefronts per SIMD, cfg3 resident in one round)
+    uint32_t rd[4];
+    int o32 = 0;
+    cnz = 0;
+#pragma unroll 1
+    for (int d = 0; d < 4; ++d) {
+      int e[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        e[t] = sbyte(pd[d], t) + uvn * (sbyte(wd[d], t) - shift);
+        o32 |= e[t] + 128;
+      }
+      rd[d] = pack4(e[0], e[1], e[2], e[3]);
+      cnz |= rd[d];
+    }
+    res = uint4{rd[0], rd[1], rd[2], rd[3]};
+    ovf |= static_cast<uint32_t>(o32) & ~255u;
+  }
+  return res;
+}
+
+// LINES: stores at 128-byte-line granularity -- a chunk is stored when any of the eight chunks of its line changed.
+// For batches that stream from HBM: a partially written line costs the memory side a read-modify-write (measured at
+// 131 072 games: 148 us with 16-byte or 64-byte stores, 130 us with whole lines, although those write 1.7x the bytes).
+// The dense pass then hands its results back through the queue and the owners store.  Cache-resident batches keep the
+// 16-byte stores straight from the dense pass (no second trip through LDS: 5.8 us against 6.2 at BASELINE config 3).
+template <int MODE, bool LINES>
+__global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyArgs a) {  // (LINES keeps the inputs to the end)
   static_assert(MODE == STEP, "s16_step_kernel: single step only");
+  constexpr int QCAP = 64;  // queue entries per wavefront
+  __shared__ __attribute__((aligned(16))) uint4 qd[kBlock / 64][QCAP];  // the candidate chunks
+  __shared__ __attribute__((aligned(8))) int2 qm[kBlock / 64][QCAP];    // (chunk index, -u_i v_j)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int64_t g = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave;
   const bool live = g < a.B;
   if (!live) g = a.B - 1;
   const int8_t* tok = a.actions + g * 48;
   const int8_t* src = a.in + g * a.in_stride + 16 * lane;
-  // every load of the wavefront is issued before anything is used
-  uint4 par[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) par[n] = *reinterpret_cast<const uint4*>(src + 1024 * n);
+  // every load of the wavefront is issued before anything is used.  (Four named chunks, not an array: hipcc keeps an
+  // array that lives to the end of the LINES variant in scratch.)
+  const uint4 p0 = *reinterpret_cast<const uint4*>(src), p1 = *reinterpret_cast<const uint4*>(src + 1024),
+              p2 = *reinterpret_cast<const uint4*>(src + 2048), p3 = *reinterpret_cast<const uint4*>(src + 3072);
   const uint4 uq = *reinterpret_cast<const uint4*>(tok);
   const uint4 wq = *reinterpret_cast<const uint4*>(tok + 32);
   const int vj = tok[16 + (lane & 15)] - a.shift;
   const int r = lane >> 4;
-  const uint32_t ud[4] = {uq.x, uq.y, uq.z, uq.w};
   uint32_t nz = 0, ovf = 0;
   const bool inplace = a.in == a.out;
-  int8_t* dst = a.out + g * a.out_stride + 16 * lane;
-  // Saturating int16 form, as in s4_step_slice: with |factor| <= 255 (int8 tokens, |shift| <= 127) u*v and
-  // (u v) w + x are formed exactly and saturate beyond int16, so everything the 16-bit form cannot represent
-  // ends outside int8 -- exactly the results that overflow.  No check of the factors; a chunk whose range
-  // test fails is redone in 32-bit by its lane (wrapped bytes + flag).
+  int8_t* const out = a.out + g * a.out_stride;
   const uint32_t shp = (static_cast<uint32_t>(a.shift) & 0xFFFFu) | (static_cast<uint32_t>(a.shift) << 16);
   const bool wide_shift = static_cast<unsigned>(a.shift + 127) > 254u;  // uniform; factors may exceed 255
   uint32_t wp[8];
   unpack_pairs(wq, wp);
 #pragma unroll
   for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
-  const uint32_t vjp = __builtin_amdgcn_perm(static_cast<uint32_t>(vj), static_cast<uint32_t>(vj), 0x05040100u);
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(ud[n]), 8 * r, 8);  // -(u_i), i = r + 4 n
-    const uint32_t uip = __builtin_amdgcn_perm(static_cast<uint32_t>(ui), static_cast<uint32_t>(ui), 0x05040100u);
-    const uint32_t pr = pk_mad_i16_sat(uip, vjp, 0u);  // (-u_i v_j) in both halves, saturated
-    uint32_t A[8];
-    unpack_pairs(par[n], A);
-#pragma unroll
-    for (int p = 0; p < 8; ++p) A[p] = pk_mad_i16_sat(pr, wp[p], A[p]);
-    uint32_t cnz = 0, c16 = 0;
-    uint4 res = pack_pairs(A, cnz, c16);
-    if (__builtin_expect(wide_shift || (c16 & 0xFF00FF00u), 0)) {  // rare: exact 32-bit form of this chunk,
-      const uint32_t wd[4] = {wq.x, wq.y, wq.z, wq.w};              // one dword at a time (the common path keeps 64 VGPRs:
-      const uint32_t pd[4] = {par[n].x, par[n].y, par[n].z, par[n].w};  // 8 wavefronts per SIMD, cfg3 resident in one round)
-      const int uv = ui * vj;
-      uint32_t rd[4];
-      int o32 = 0;
-      cnz = 0;
-#pragma unroll 1
-      for (int d = 0; d < 4; ++d) {
-        int e[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          e[t] = sbyte(pd[d], t) + uv * (sbyte(wd[d], t) - a.shift);
-          o32 |= e[t] + 128;
-        }
-        rd[d] = pack4(e[0], e[1], e[2], e[3]);
-        cnz |= rd[d];
+  auto differs = [](const uint4& x, const uint4& y) { return x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w; };
+  // does this lane store chunk (lane, n), given whether it changed and the ballot of the lanes whose chunk n changed?
+  auto stores = [&](bool changed, unsigned long long cm) {
+    if (!inplace) return true;  // out of place everything is written
+    return LINES ? ((cm >> (lane & ~7)) & 0xFFull) != 0 : changed;
+  };
+
+  // ---- which of the lane's rows does the action touch?  candidates -> the wavefront's queue ----
+  int total = 0;  // uniform
+  auto enqueue = [&](int n, const uint4& pn, uint32_t udw, int& uvn, int& slot) {
+    const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(udw), 8 * r, 8);  // -(u_i), i = r + 4 n
+    uvn = ui * vj;
+    const bool cand = uvn != 0;
+    const unsigned long long m = __ballot(cand);
+    slot = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
+    if (cand) {
+      if (slot < QCAP) {
+        qd[wave][slot] = pn;
+        qm[wave][slot] = int2{lane + 64 * n, uvn};
       }
-      res = uint4{rd[0], rd[1], rd[2], rd[3]};
-      ovf |= static_cast<uint32_t>(o32) & ~255u;
+    } else {
+      nz |= pn.x | pn.y | pn.z | pn.w;
+      if (!LINES && !inplace && live) *reinterpret_cast<uint4*>(out + 16 * (lane + 64 * n)) = pn;
     }
-    nz |= cnz;
-    // stored as soon as it is final; in place, rows the action left untouched need no store
-    const bool same = inplace && res.x == par[n].x && res.y == par[n].y && res.z == par[n].z && res.w == par[n].w;
-    if (live && !same) *reinterpret_cast<uint4*>(dst + 1024 * n) = res;
+    total += __builtin_popcountll(m);
+  };
+  int uv0, uv1, uv2, uv3, s0, s1, s2, s3;
+  enqueue(0, p0, uq.x, uv0, s0);
+  enqueue(1, p1, uq.y, uv1, s1);
+  enqueue(2, p2, uq.z, uv2, s2);
+  enqueue(3, p3, uq.w, uv3, s3);
+  if (total <= QCAP) {
+    // ---- dense pass: lane k takes entry k (LDS serves one wavefront's accesses in order: no barrier) ----
+    __builtin_amdgcn_wave_barrier();
+    if (lane < total) {
+      const uint4 x = qd[wave][lane];
+      const int2 me = qm[wave][lane];
+      uint32_t cnz;
+      const uint4 res = s16_chunk(x, me.y, wp, wq, a.shift, wide_shift, cnz, ovf);
+      nz |= cnz;
+      if constexpr (LINES) {
+        qd[wave][lane] = res;  // back to the owner, who stores whole lines
+      } else {
+        // in place, a row the action left as it was (w zero there, or wrapped back) needs no store
+        if (live && (!inplace || differs(res, x))) *reinterpret_cast<uint4*>(out + 16 * me.x) = res;
+      }
+    }
+    if constexpr (LINES) {
+      __builtin_amdgcn_wave_barrier();
+      auto finish = [&](int n, const uint4& pn, int uvn, int slot) {
+        uint4 res = pn;
+        if (uvn != 0) res = qd[wave][slot];
+        const bool chg = differs(res, pn);
+        if (live && stores(chg, __ballot(chg))) *reinterpret_cast<uint4*>(out + 16 * (lane + 64 * n)) = res;
+      };
+      finish(0, p0, uv0, s0);
+      finish(1, p1, uv1, s1);
+      finish(2, p2, uv2, s2);
+      finish(3, p3, uv3, s3);
+    }
+  } else {
+    // ---- dense factors: every candidate chunk by its own lane ----
+    auto direct = [&](int n, const uint4& pn, int uvn) {
+      uint4 res = pn;
+      if (uvn != 0) {
+        uint32_t cnz;
+        res = s16_chunk(pn, uvn, wp, wq, a.shift, wide_shift, cnz, ovf);
+        nz |= cnz;
+      }
+      const bool chg = differs(res, pn);
+      const bool st = LINES ? stores(chg, __ballot(chg)) : (uvn != 0 && (chg || !inplace));
+      if (live && st) *reinterpret_cast<uint4*>(out + 16 * (lane + 64 * n)) = res;
+    };
+    direct(0, p0, uv0);
+    direct(1, p1, uv1);
+    direct(2, p2, uv2);
+    direct(3, p3, uv3);
   }
   const bool any_nz = __ballot(nz != 0) != 0;
   const bool any_ovf = __ballot(ovf != 0) != 0;
@@ -1368,7 +1461,21 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
       const int64_t blocks = (B + 3) / 4;
       if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
       (void)hipGetLastError();
-      hipLaunchKernelGGL((s16_step_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+      // whole-line stores pay from ~100 MiB of states on (measured: 6.0 / 7.0 us at 32 MiB, 26.3 / 25.5 at 128 MiB,
+      // 50.3 / 47.0 at 256 MiB, 150 / 128 at 512 MiB, 16-byte stores / whole lines)
+      if (B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES"))  // (A/B switch: tests at small batches)
+        hipLaunchKernelGGL((s16_step_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+      else
+        hipLaunchKernelGGL((s16_step_kernel<MODE, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+      return check_launch(fn);
+    }
+  }
+  const bool no_s25 = TG_SWITCH("TG_NO_S25_DIRECT");  // A/B switch for measurements
+  if constexpr (MODE == STEP) {
+    // (|shift| <= 127: factors within +-255, which the 32-bit redo of s25_step_kernel takes from its int16 tables)
+    if (al && a.S == 25 && a.shift >= -127 && a.shift <= 127 && B <= 0x7fffffffLL && !force_i32 && !no_s25) {
+      (void)hipGetLastError();
+      hipLaunchKernelGGL(s25_step_kernel, dim3((unsigned)B), dim3(kBlock), 0, st, a);
       return check_launch(fn);
     }
   }

@@ -357,6 +357,23 @@ __device__ __forceinline__ uint32_t abs4_i8(uint32_t x) {
   return (x ^ (s1 * 0xFFu)) + s1;
 }
 
+// Diagnostic build only (-DTG_STAMPS, tools/stamp_many.py): workgroups 0, 64, .., 960 record the shader clock (s_memtime,
+// 2.4 GHz) at phase boundaries into the OVERFLOW buffer (32 uint64 per workgroup; B >= 4096), which this kernel never
+// writes otherwise; slots 0 and 31 hold s_memrealtime (100 MHz, one counter for the whole chip) at entry and exit.
+#ifdef TG_STAMPS
+#define TG_MSTAMP(i)                                                                                        \
+  do {                                                                                                      \
+    const int tg_stamp_i = (i);                                                                             \
+    if ((blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 16 && threadIdx.x == 0 && tg_stamp_i < 32 && a.overflow) \
+      reinterpret_cast<unsigned long long*>(a.overflow)[(blockIdx.x >> 6) * 32 + tg_stamp_i] =              \
+          (tg_stamp_i == 0 || tg_stamp_i == 31) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define TG_MSTAMP(i) \
+  do {               \
+  } while (0)
+#endif
+
 template <int S, int KS>
 __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int Rp) {
   using G = MGeo<S>;
@@ -423,7 +440,11 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
 
   if (tid < 8) red[tid] = 0;
   int orpar = 0;
+  int stamp = 2;
+  (void)stamp;
+  TG_MSTAMP(0);
   __syncthreads();
+  TG_MSTAMP(1);
   for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
     // ---- 1. factors (u negated: the products are subtracted), transposed into LDS; X0 into the image ----
     const __amdgpu_buffer_rsrc_t tok = __builtin_amdgcn_make_buffer_rsrc(
@@ -463,7 +484,9 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
     // workgroup OR of `big` with ONE barrier (HIP's __syncthreads_or costs three): red[4 + parity] was cleared during
     // the previous game, is OR-ed here, read after the barrier; the other word is cleared for the next game
     if (big) atomicOr(reinterpret_cast<unsigned*>(&red[4 + orpar]), 1u);
+    TG_MSTAMP(stamp++);  // staged (own part)
     __syncthreads();
+    TG_MSTAMP(stamp++);  // B1 passed
     const bool anybig = red[4 + orpar] != 0;
     if (tid == 0) red[4 + (orpar ^ 1)] = 0;
     orpar ^= 1;
@@ -496,6 +519,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
         smx[wave * Rp + r] = mx;
       }
     }
+    TG_MSTAMP(stamp++);  // scalars (own part)
     __syncthreads();
     // every wavefront: sum_r mu_r mv_r mw_r.  Above 127 the overflow bound cannot hold whatever the final state
     // is: hand the game over now, before the expensive part
@@ -508,6 +532,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       if (bound > (1 << 24)) bound = 1 << 24;
     }
     const bool wide = bound > 127;  // workgroup-uniform: the scalar bound cannot certify this game
+    TG_MSTAMP(stamp++);  // barrier + scalar bound
     if (wide) {
       // ---- elementwise bound: Bnd = |X0| + sum_r |u_r| (x) |v_r| (x) |w_r|, the same tiles on absolute values ----
       for (int e = 16 * tid; e < G::TROWS * RS; e += 16 * kBlock) {
@@ -660,7 +685,9 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
     if (hx1) atomicAdd(reinterpret_cast<unsigned*>(&red[1]), hx1);
     const int mabs = max(hi, -lo);
     if (mabs) atomicMax(&red[2], mabs);
+    TG_MSTAMP(stamp++);  // tiles (own part; elementwise pass included when wide)
     __syncthreads();  // image, action scalars and reductions complete
+    TG_MSTAMP(stamp++);  // B2 passed
 
     // ---- 3. verdict (every wavefront computes it: no further exchange) ----
     bool redo;
@@ -700,6 +727,9 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       a.done_step[g] = redo ? kNeedsExact : dstep;
       if (redo) atomicAdd(&g_many_handovers, 1ull);
     }
+    TG_MSTAMP(stamp++);  // verdict + stores issued
     __syncthreads();
   }
+  TG_MSTAMP(stamp++);
+  TG_MSTAMP(31);
 }

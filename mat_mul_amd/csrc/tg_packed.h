@@ -599,3 +599,128 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
     }
   }
 }
+
+// =============================================================================================
+// S = 25 single step without the staging round trip of packed_kernel (STEP, one action, one workgroup per game).
+// packed_kernel brings the raw tokens to LDS, scans them (barrier), turns them into the int16 tables (barrier),
+// computes, and ORs done / overflow (barrier).  Here each of the 136 table entries is loaded straight from the
+// game's 75 tokens by the thread that writes it -- issued together with the thread's four state chunks, so the
+// wavefront's chain is ONE memory round trip -> table -> barrier -> arithmetic -> stores -> the done / overflow OR.
+// No range prescan: the saturating 16-bit form (as in s16_step_kernel) is exact or lands outside int8, and a chunk
+// whose range test fails is redone by its lane in 32 bits from the same tables (|factor| <= 255: host-checked shift).
+// Geometry and tables are packed_kernel's (period trick, two row segments per window).
+// =============================================================================================
+__global__ __launch_bounds__(kBlock, 8) void s25_step_kernel(ApplyArgs a) {
+  constexpr int S = 25;
+  using G = PGeo<S, kBlock>;
+  static_assert(G::NSEG == 2 && G::NCH == 4 && G::FSTRIDE <= kBlock, "s25_step_kernel geometry");
+  __shared__ __attribute__((aligned(16))) short F[(G::FSTRIDE + 7) & ~7];
+  __shared__ __attribute__((aligned(16))) uint32_t or_slots[4];
+  const int lt = threadIdx.x;
+  const int64_t g = blockIdx.x;
+  const int8_t* const tok = a.actions + g * (3 * S);
+  // ---- every load of the thread is issued before anything is used: its token FIRST (vmcnt retires in order: the
+  // table and the barrier then run while the four state chunks are still on their way) ----
+  // table entry `lt`: -u[0..S), 0, v[0..S), pad, two periodic copies of w (the second shifted by one)
+  int sidx = -1;
+  if (lt < S) {
+    sidx = lt;
+  } else if (lt > S && lt <= 2 * S) {
+    sidx = S + (lt - S - 1);
+  } else if (lt >= G::UVLEN && lt < G::FSTRIDE) {
+    int q = lt - G::UVLEN;
+    const int copy = q >= G::WE;
+    q -= copy * G::WE;
+    sidx = 2 * S + (q + copy) % S;
+  }
+  const int tokv = tok[sidx >= 0 ? sidx : 0];
+  const bool active = lt < G::TSA;
+  uint4 par[G::NCH];
+  bool cv[G::NCH];
+#pragma unroll
+  for (int n = 0; n < G::NCH; ++n) {
+    const int c = lt + G::TSA * n;
+    cv[n] = active && c < G::NCHUNK;
+    par[n] = uint4{0, 0, 0, 0};
+    if (cv[n]) par[n] = load_chunk<G::TAIL>(a.in + g * a.in_stride + 16 * c, G::TAIL != 0 && c == G::NCHUNK - 1);
+  }
+  if (lt < G::FSTRIDE) {
+    int val = sidx >= 0 ? tokv - a.shift : 0;
+    if (lt < S) val = -val;
+    F[lt] = static_cast<short>(val);
+  }
+  // lane geometry (constant over the lane's chunks): window position and the split between its two rows
+  const int l0 = (16 * lt) % S;
+  const int woff = G::UVLEN + (l0 & 1) * G::WE + (l0 & ~1);
+  const int hi = S - l0;  // elements k < hi belong to the window's first row
+  __syncthreads();
+  uint32_t ws[2][8], wraw[8];
+  {
+    const uint32_t* wp = reinterpret_cast<const uint32_t*>(F + woff);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint32_t m = ((2 * p < hi) ? 0x0000FFFFu : 0u) | ((2 * p + 1 < hi) ? 0xFFFF0000u : 0u);
+      wraw[p] = wp[p];
+      ws[0][p] = wraw[p] & m;
+      ws[1][p] = wraw[p] & ~m;
+    }
+  }
+  uint32_t nz = 0, ovf = 0;
+  const bool inplace = a.in == a.out;
+#pragma unroll
+  for (int n = 0; n < G::NCH; ++n) {
+    const int c = lt + G::TSA * n;
+    const int r0 = (16 * c) / S;  // row (i, j) of the chunk's first element; the second segment lies in row r0 + 1
+    int uv[2];
+#pragma unroll
+    for (int sgm = 0; sgm < 2; ++sgm) {
+      const int row = r0 + sgm;
+      int i = row / S;
+      const int j = row - i * S;
+      if (!cv[n] || i >= S) i = S;  // F[S] == 0: rows past the tensor (and idle chunks) add nothing
+      uv[sgm] = mul24_pinned(F[i], F[S + 1 + j]);
+    }
+    uint32_t A[8];
+    unpack_pairs(par[n], A);
+#pragma unroll
+    for (int sgm = 0; sgm < 2; ++sgm) {
+      // |u v| may exceed int16: clamp the multiplier; the product then saturates and the range test below fails
+      const int cl = max(-32767, min(32767, uv[sgm]));
+      const uint32_t pr = __builtin_amdgcn_perm(static_cast<uint32_t>(cl), static_cast<uint32_t>(cl), 0x05040100u);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) A[p] = pk_mad_i16_sat(pr, ws[sgm][p], A[p]);
+    }
+    uint32_t cnz = 0, c16 = 0;
+    uint4 res = pack_pairs(A, cnz, c16);
+    if (__builtin_expect((c16 & 0xFF00FF00u) != 0, 0)) {  // rare: the chunk again in 32 bits (wrapped bytes + flag)
+      const uint32_t pd[4] = {par[n].x, par[n].y, par[n].z, par[n].w};
+      uint32_t rd[4];
+      int o32 = 0;
+      cnz = 0;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {  // (unrolled: a dynamically indexed wraw[] would be moved to LDS)
+        int e[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int k = 4 * d + t;
+          const int w = static_cast<short>(wraw[k >> 1] >> (16 * (k & 1)));
+          e[t] = sbyte(pd[d], t) + (k < hi ? uv[0] : uv[1]) * w;
+          o32 |= e[t] + 128;
+        }
+        rd[d] = pack4(e[0], e[1], e[2], e[3]);
+        cnz |= rd[d];
+      }
+      res = uint4{rd[0], rd[1], rd[2], rd[3]};
+      ovf |= static_cast<uint32_t>(o32) & ~255u;
+    }
+    nz |= cnz;
+    // in place, a chunk the action did not touch needs no store
+    const bool same = inplace && res.x == par[n].x && res.y == par[n].y && res.z == par[n].z && res.w == par[n].w;
+    if (cv[n] && !same) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * c, res, G::TAIL != 0 && c == G::NCHUNK - 1);
+  }
+  const uint32_t both = block_or2((nz != 0 ? 1u : 0u) | (ovf != 0 ? 2u : 0u), or_slots);
+  if (lt == 0) {
+    a.done[g] = (both & 1u) ? 0 : 1;
+    if (a.overflow && (both & 2u)) a.overflow[g] = 1;
+  }
+}

@@ -93,6 +93,44 @@ print("SPARSE_OK")
 '''
 
 
+STEP_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from mat_mul_amd import ops, _lib
+from oracle import tensor_game as O
+assert _lib.AB_VARIANT
+DEV = "cuda:0"
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+host = lambda t: t.detach().cpu().numpy()
+def padded(st):
+    t = ops.alloc_states(st.shape[0], st.shape[1], DEV); t.copy_(torch.from_numpy(np.ascontiguousarray(st))); return t
+for S, B in [(16, 1), (16, 3), (16, 131), (25, 2), (25, 37)]:
+    rng = np.random.default_rng(S * 7 + B)
+    for case in ("sparse", "dense", "wide", "overflow", "null"):
+        st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+        ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)).astype(np.int8)
+        if case == "dense":
+            ac = rng.integers(0, 3, size=(B, 3 * S)).astype(np.int8)          # > 64 candidate rows per game
+        if case == "wide":
+            ac[::2] = rng.integers(-128, 128, size=ac[::2].shape)                # beyond the 16-bit form
+        if case == "overflow":
+            st = rng.choice([-128, 127, 0, 1], size=st.shape).astype(np.int8)
+        if case == "null":
+            ac[:, :S] = 1                                                        # u == 0: nothing changes
+            st[::2] = 0                                                          # and these are already done
+        for shift in ((1, -2, 127) if case == "wide" else (1,)):
+            want, want_done, want_ovf = O.step_i8(st, ac, shift=shift)
+            for inplace in (False, True):
+                t = padded(st)
+                ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+                out, done = ops.step(t, dev(ac), out=t if inplace else None, overflow=ovf, shift=shift)
+                assert np.array_equal(host(out), want), (S, B, case, shift, inplace)
+                assert np.array_equal(host(done), want_done) and np.array_equal(host(ovf), want_ovf), (S, B, case, shift, inplace)
+                assert inplace or np.array_equal(host(t), st)
+print("STEP_OK")
+'''
+
+
 def _run(script_text, tmp_path, marker, extra_env=None):
     script = tmp_path / "ab_case.py"
     script.write_text(script_text)
@@ -106,6 +144,14 @@ def test_ab_switch_paths_stay_exact(env_name, tmp_path):
     """The measurement switches (32-bit cursor kernels; packed chunks instead of rows; vector ALU instead of
     the matrix cores) select kernels that the product dispatch no longer uses -- they must stay bit-exact."""
     _run(AB_SCRIPT, tmp_path, "AB_OK", {env_name: "1"})
+
+
+@pytest.mark.parametrize("env_name", ["TG_S16_LINES", "TG_NO_S25_DIRECT", "TG_NO_S16_DIRECT"])
+def test_single_step_variants_stay_exact(env_name, tmp_path):
+    """The S=16 step with whole-line stores (the product takes it from 96 MiB of states on; forced here at small
+    batches), and the staged kernels that the direct S=16 / S=25 step kernels replaced: sparse, dense (more candidate
+    rows than the queue holds), wide-factor, overflowing and null actions, in place and out of place."""
+    _run(STEP_SCRIPT, tmp_path, "STEP_OK", {env_name: "1"})
 
 
 def test_step_sparse_rollout_matches_dense(tmp_path):

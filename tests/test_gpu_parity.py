@@ -173,6 +173,36 @@ def test_step_matches_oracle(S, B):
     assert want_done.sum() >= 1
 
 
+@pytest.mark.parametrize("S,B", [(16, 1), (16, 130), (25, 1), (25, 21), (16, 24576)])
+def test_step_direct_kernels_sparse_dense_null_actions(S, B):
+    """The direct S=16 / S=25 step kernels: sparse actions (S=16: the compacted queue), dense ones (more candidate rows
+    than the queue holds: every chunk by its own lane), null actions, finished games; in place and out of place.
+    B = 24 576 at S=16 is 96 MiB of states: the variant that stores whole 128-byte lines."""
+    rng = np.random.default_rng(S * 31 + B)
+    for case in (("sparse", "dense", "null") if B < 1000 else ("sparse",)):
+        st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+        ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)).astype(np.int8)
+        if case == "dense":
+            ac = rng.integers(0, 3, size=(B, 3 * S)).astype(np.int8)
+        if case == "null":
+            ac[:, :S] = 1
+            st[::2] = 0
+        if B >= 1000:  # a few dense and a few finishing games inside the big batch
+            ac[::97] = rng.integers(0, 3, size=ac[::97].shape)
+            st[5::101] = O.gen_from_factors_i8(ac[5::101, None, :])[0]
+        want, want_done, want_ovf = O.step_i8(st, ac)
+        assert not want_ovf.any()
+        for inplace in (False, True):
+            t = padded(st)
+            ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+            out, done = ops.step(t, dev(ac), out=t if inplace else None, overflow=ovf)
+            assert np.array_equal(host(out), want), (S, B, case, inplace)
+            assert np.array_equal(host(done), want_done) and not host(ovf).any(), (S, B, case, inplace)
+            assert inplace or np.array_equal(host(t), st)
+        assert case != "null" or want_done[::2].all()
+        assert B < 1000 or want_done[5::101].all()
+
+
 @pytest.mark.parametrize("S", [4, 9, 16, 25, 6])
 def test_step_wide_tokens_and_overflow(S):
     rng = np.random.default_rng(77 + S)
@@ -1202,22 +1232,31 @@ def test_step_stream_hand_off_is_visible_while_the_kernel_runs(S, B):
     prog = torch.zeros(n_units, dtype=torch.int32, device=DEV)
     done = torch.zeros((K, B), dtype=torch.uint8, device=DEV)
     torch.cuda.synchronize()
-    side = torch.cuda.Stream()
+    # The stepper runs on a normal-priority stream, the consumer on a HIGH-priority one: HIP keeps separate hardware
+    # queues per priority, so the consumer's small kernels never queue up behind the resident stepper (two streams of
+    # the same priority may share a hardware queue -- then nothing of the consumer runs until the stepper's bounded
+    # wait expires).
+    side, cons = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
     with torch.cuda.stream(side):
         ops.step_stream(t, acd, done=done, ready=ready, progress=prog, status=status)
     import time
     cur = st.copy()
-    for k in range(K):
-        t0 = time.time()
-        while int(prog.min()) < k:                                   # (a tiny kernel + copy on the default stream)
-            assert time.time() - t0 < 20, "the stepper made no progress"
-        seen = host(t.clone())                                        # read while the stepper is resident
-        assert np.array_equal(seen, cur), (S, k)
-        if k:
-            assert np.array_equal(host(done[k - 1].clone()), want_done), (S, k)
-        cur, want_done, _ = O.step_i8(cur, ac[k])
-        ready[k:k + 1].fill_(1)
-        torch.cuda.current_stream().synchronize()
+    with torch.cuda.stream(cons):
+        for k in range(K):
+            t0 = time.time()
+            while int(prog.min()) < k:                                   # (a tiny kernel + copy on the consumer stream)
+                if time.time() - t0 > 20:
+                    side.synchronize()
+                    if int(status[0]) == 1:
+                        pytest.skip("consumer and stepper were not scheduled concurrently (the stepper timed out as designed)")
+                    raise AssertionError("the stepper made no progress")
+            seen = host(t.clone())                                        # read while the stepper is resident
+            assert np.array_equal(seen, cur), (S, k)
+            if k:
+                assert np.array_equal(host(done[k - 1].clone()), want_done), (S, k)
+            cur, want_done, _ = O.step_i8(cur, ac[k])
+            ready[k:k + 1].fill_(1)
+            cons.synchronize()
     side.synchronize()
     assert int(status[0]) == 0 and np.array_equal(host(t), cur) and bool((prog == K).all())
 
