@@ -609,16 +609,26 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
 // No range prescan: the saturating 16-bit form (as in s16_step_kernel) is exact or lands outside int8, and a chunk
 // whose range test fails is redone by its lane in 32 bits from the same tables (|factor| <= 255: host-checked shift).
 // Geometry and tables are packed_kernel's (period trick, two row segments per window).
+// Arithmetic only where the action acts, as in s16_step_kernel: a chunk is a candidate when one of the (at most two)
+// rows it touches has u_i v_j != 0 (~14 % of the chunks under the reference's factor distribution); each wavefront
+// compacts its candidates (16 bytes, chunk index, the two products) into a 64-entry LDS queue, and in one dense pass
+// lane k takes entry k: window from the table at the chunk's own position, arithmetic, store.  Unchanged chunks only
+// feed the zero test.  A wavefront with more than 64 candidates does its chunks directly.
 // =============================================================================================
-__global__ __launch_bounds__(kBlock, 8) void s25_step_kernel(ApplyArgs a) {
+__global__ __launch_bounds__(kBlock, 7) void s25_step_kernel(ApplyArgs a) {  // (6 spills at 64 VGPRs)
   constexpr int S = 25;
   using G = PGeo<S, kBlock>;
   static_assert(G::NSEG == 2 && G::NCH == 4 && G::FSTRIDE <= kBlock, "s25_step_kernel geometry");
+  constexpr int QCAP = 64;
   __shared__ __attribute__((aligned(16))) short F[(G::FSTRIDE + 7) & ~7];
   __shared__ __attribute__((aligned(16))) uint32_t or_slots[4];
-  const int lt = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint4 qd[kBlock / 64][QCAP];  // candidate chunks
+  __shared__ __attribute__((aligned(16))) int4 qm[kBlock / 64][QCAP];   // (chunk index, uv of its first row, of its second row, -)
+  const int lt = threadIdx.x, lane = lt & 63, wave = lt >> 6;
   const int64_t g = blockIdx.x;
   const int8_t* const tok = a.actions + g * (3 * S);
+  const int8_t* const in = a.in + g * a.in_stride;
+  int8_t* const out = a.out + g * a.out_stride;
   // ---- every load of the thread is issued before anything is used: its token FIRST (vmcnt retires in order: the
   // table and the barrier then run while the four state chunks are still on their way) ----
   // table entry `lt`: -u[0..S), 0, v[0..S), pad, two periodic copies of w (the second shifted by one)
@@ -635,65 +645,45 @@ __global__ __launch_bounds__(kBlock, 8) void s25_step_kernel(ApplyArgs a) {
   }
   const int tokv = tok[sidx >= 0 ? sidx : 0];
   const bool active = lt < G::TSA;
-  uint4 par[G::NCH];
-  bool cv[G::NCH];
-#pragma unroll
-  for (int n = 0; n < G::NCH; ++n) {
+  // (four named chunks, not an array: see s16_step_kernel)
+  auto load = [&](int n) {
     const int c = lt + G::TSA * n;
-    cv[n] = active && c < G::NCHUNK;
-    par[n] = uint4{0, 0, 0, 0};
-    if (cv[n]) par[n] = load_chunk<G::TAIL>(a.in + g * a.in_stride + 16 * c, G::TAIL != 0 && c == G::NCHUNK - 1);
-  }
+    uint4 q = uint4{0, 0, 0, 0};
+    if (active && c < G::NCHUNK) q = load_chunk<G::TAIL>(in + 16 * c, G::TAIL != 0 && c == G::NCHUNK - 1);
+    return q;
+  };
+  const uint4 p0 = load(0), p1 = load(1), p2 = load(2), p3 = load(3);
   if (lt < G::FSTRIDE) {
     int val = sidx >= 0 ? tokv - a.shift : 0;
     if (lt < S) val = -val;
     F[lt] = static_cast<short>(val);
   }
-  // lane geometry (constant over the lane's chunks): window position and the split between its two rows
-  const int l0 = (16 * lt) % S;
-  const int woff = G::UVLEN + (l0 & 1) * G::WE + (l0 & ~1);
-  const int hi = S - l0;  // elements k < hi belong to the window's first row
-  __syncthreads();
-  uint32_t ws[2][8], wraw[8];
-  {
-    const uint32_t* wp = reinterpret_cast<const uint32_t*>(F + woff);
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const uint32_t m = ((2 * p < hi) ? 0x0000FFFFu : 0u) | ((2 * p + 1 < hi) ? 0xFFFF0000u : 0u);
-      wraw[p] = wp[p];
-      ws[0][p] = wraw[p] & m;
-      ws[1][p] = wraw[p] & ~m;
-    }
-  }
-  uint32_t nz = 0, ovf = 0;
   const bool inplace = a.in == a.out;
+  uint32_t nz = 0, ovf = 0;
+  auto differs = [](const uint4& x, const uint4& y) { return x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w; };
+  // one chunk c with the products of its two rows: x + uv * w over the window at the chunk's position
+  auto chunk = [&](const uint4& x, int c, int uv0, int uv1, uint32_t& cnz) {
+    const int l0 = (16 * c) % S, hi = S - l0;  // elements k < hi belong to the window's first row
+    const uint32_t* wp = reinterpret_cast<const uint32_t*>(F + G::UVLEN + (l0 & 1) * G::WE + (l0 & ~1));
+    uint32_t wraw[8];
 #pragma unroll
-  for (int n = 0; n < G::NCH; ++n) {
-    const int c = lt + G::TSA * n;
-    const int r0 = (16 * c) / S;  // row (i, j) of the chunk's first element; the second segment lies in row r0 + 1
-    int uv[2];
-#pragma unroll
-    for (int sgm = 0; sgm < 2; ++sgm) {
-      const int row = r0 + sgm;
-      int i = row / S;
-      const int j = row - i * S;
-      if (!cv[n] || i >= S) i = S;  // F[S] == 0: rows past the tensor (and idle chunks) add nothing
-      uv[sgm] = mul24_pinned(F[i], F[S + 1 + j]);
-    }
+    for (int p = 0; p < 8; ++p) wraw[p] = wp[p];
+    // |u v| may exceed int16: clamp the multiplier; the product then saturates and the range test below fails
+    const int c0 = max(-32767, min(32767, uv0)), c1 = max(-32767, min(32767, uv1));
+    const uint32_t pr0 = __builtin_amdgcn_perm(static_cast<uint32_t>(c0), static_cast<uint32_t>(c0), 0x05040100u);
+    const uint32_t pr1 = __builtin_amdgcn_perm(static_cast<uint32_t>(c1), static_cast<uint32_t>(c1), 0x05040100u);
     uint32_t A[8];
-    unpack_pairs(par[n], A);
+    unpack_pairs(x, A);
 #pragma unroll
-    for (int sgm = 0; sgm < 2; ++sgm) {
-      // |u v| may exceed int16: clamp the multiplier; the product then saturates and the range test below fails
-      const int cl = max(-32767, min(32767, uv[sgm]));
-      const uint32_t pr = __builtin_amdgcn_perm(static_cast<uint32_t>(cl), static_cast<uint32_t>(cl), 0x05040100u);
-#pragma unroll
-      for (int p = 0; p < 8; ++p) A[p] = pk_mad_i16_sat(pr, ws[sgm][p], A[p]);
+    for (int p = 0; p < 8; ++p) {  // the pair's multiplier: first row below hi, second row from hi on (one pair may straddle)
+      const uint32_t pr = (2 * p + 1 < hi) ? pr0 : ((2 * p >= hi) ? pr1 : __builtin_amdgcn_perm(pr1, pr0, 0x07060100u));
+      A[p] = pk_mad_i16_sat(pr, wraw[p], A[p]);
     }
-    uint32_t cnz = 0, c16 = 0;
+    uint32_t c16 = 0;
+    cnz = 0;
     uint4 res = pack_pairs(A, cnz, c16);
     if (__builtin_expect((c16 & 0xFF00FF00u) != 0, 0)) {  // rare: the chunk again in 32 bits (wrapped bytes + flag)
-      const uint32_t pd[4] = {par[n].x, par[n].y, par[n].z, par[n].w};
+      const uint32_t pd[4] = {x.x, x.y, x.z, x.w};
       uint32_t rd[4];
       int o32 = 0;
       cnz = 0;
@@ -704,7 +694,7 @@ __global__ __launch_bounds__(kBlock, 8) void s25_step_kernel(ApplyArgs a) {
         for (int t = 0; t < 4; ++t) {
           const int k = 4 * d + t;
           const int w = static_cast<short>(wraw[k >> 1] >> (16 * (k & 1)));
-          e[t] = sbyte(pd[d], t) + (k < hi ? uv[0] : uv[1]) * w;
+          e[t] = sbyte(pd[d], t) + (k < hi ? uv0 : uv1) * w;
           o32 |= e[t] + 128;
         }
         rd[d] = pack4(e[0], e[1], e[2], e[3]);
@@ -713,10 +703,69 @@ __global__ __launch_bounds__(kBlock, 8) void s25_step_kernel(ApplyArgs a) {
       res = uint4{rd[0], rd[1], rd[2], rd[3]};
       ovf |= static_cast<uint32_t>(o32) & ~255u;
     }
+    return res;
+  };
+  __syncthreads();
+
+  // ---- which of the lane's chunks does the action touch?  candidates -> the wavefront's queue ----
+  int total = 0;  // wave-uniform
+  auto enqueue = [&](int n, const uint4& pn, int& uv0, int& uv1) {
+    const int c = lt + G::TSA * n;
+    const bool cv = active && c < G::NCHUNK;
+    const int r0 = (16 * c) / S, l0 = (16 * c) % S;  // row (i, j) of the chunk's first element; the second row is r0 + 1
+    int uv[2];
+#pragma unroll
+    for (int sgm = 0; sgm < 2; ++sgm) {
+      const int row = r0 + sgm;
+      int i = row / S;
+      const int j = row - i * S;
+      if (!cv || i >= S) i = S;  // F[S] == 0: rows past the tensor (and idle chunks) add nothing
+      uv[sgm] = mul24_pinned(F[i], F[S + 1 + j]);
+    }
+    if (l0 + 16 <= S) uv[1] = 0;  // the window does not reach the second row
+    uv0 = uv[0];
+    uv1 = uv[1];
+    const bool cand = (uv0 | uv1) != 0;
+    const unsigned long long m = __ballot(cand);
+    const int slot = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
+    if (cand) {
+      if (slot < QCAP) {
+        qd[wave][slot] = pn;
+        qm[wave][slot] = int4{c, uv0, uv1, 0};
+      }
+    } else {
+      nz |= pn.x | pn.y | pn.z | pn.w;
+      if (!inplace && cv) store_chunk<G::TAIL>(out + 16 * c, pn, G::TAIL != 0 && c == G::NCHUNK - 1);
+    }
+    total += __builtin_popcountll(m);
+  };
+  int u00, u01, u10, u11, u20, u21, u30, u31;
+  enqueue(0, p0, u00, u01);
+  enqueue(1, p1, u10, u11);
+  enqueue(2, p2, u20, u21);
+  enqueue(3, p3, u30, u31);
+  auto finish = [&](const uint4& x, int c, int uv0, int uv1) {
+    uint32_t cnz;
+    const uint4 res = chunk(x, c, uv0, uv1, cnz);
     nz |= cnz;
-    // in place, a chunk the action did not touch needs no store
-    const bool same = inplace && res.x == par[n].x && res.y == par[n].y && res.z == par[n].z && res.w == par[n].w;
-    if (cv[n] && !same) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * c, res, G::TAIL != 0 && c == G::NCHUNK - 1);
+    // in place, a chunk the action left as it was needs no store
+    if (!inplace || differs(res, x)) store_chunk<G::TAIL>(out + 16 * c, res, G::TAIL != 0 && c == G::NCHUNK - 1);
+  };
+  if (total <= QCAP) {
+    // ---- dense pass: lane k takes entry k (LDS serves one wavefront's accesses in order: no barrier) ----
+    __builtin_amdgcn_wave_barrier();
+    if (lane < total) {
+      const uint4 x = qd[wave][lane];
+      const int4 me = qm[wave][lane];
+      finish(x, me.x, me.y, me.z);
+    }
+  } else {
+    // ---- dense factors: every candidate chunk by its own lane ----
+    if ((u00 | u01) != 0) finish(p0, lt, u00, u01);
+    if ((u10 | u11) != 0) finish(p1, lt + G::TSA, u10, u11);
+    if ((u20 | u21) != 0) finish(p2, lt + 2 * G::TSA, u20, u21);
+    if ((u30 | u31) != 0) finish(p3, lt + 3 * G::TSA, u30, u31);
   }
   const uint32_t both = block_or2((nz != 0 ? 1u : 0u) | (ovf != 0 ? 2u : 0u), or_slots);
   if (lt == 0) {

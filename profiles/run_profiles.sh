@@ -38,4 +38,10 @@ done
 hipcc -O3 -std=c++17 --offload-arch=gfx950 $R/tools/microbench_step.hip -L$R/mat_mul_amd/lib -ltensorgame -o $OUT/microbench_step > $OUT/microbench_build.log 2>&1 || exit 1
 LD_LIBRARY_PATH=$R/mat_mul_amd/lib:$LD_LIBRARY_PATH $OUT/microbench_step 65536 2000 > $OUT/launch_floor.txt 2> $OUT/launch_floor.err || exit 1
 rm -f $OUT/microbench_step
+# 7. chip probes behind DESIGN.md's bounds: read-only and copy bandwidth, issue rates, shader clock
+for t in read_bw_probe issue_rate_probe shader_clock_probe; do
+  hipcc -O3 --offload-arch=gfx950 $R/tools/$t.hip -o $OUT/$t > $OUT/${t}_build.log 2>&1 || exit 1
+  $OUT/$t > $OUT/$t.txt 2> $OUT/$t.err || exit 1
+  rm -f $OUT/$t
+done
 echo profiles done

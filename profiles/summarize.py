@@ -62,6 +62,9 @@ for name in ("bench_driver", "bench_graph", "bench_graph_S16", "bench_eager", "b
 lf = src / "launch_floor.txt"
 if lf.exists():
     shutil.copy(lf, dst / f"{tag}_launch_floor.txt")
+for probe, name in (("read_bw_probe", "read_bandwidth"), ("issue_rate_probe", "issue_rates"), ("shader_clock_probe", "shader_clock")):
+    if (src / f"{probe}.txt").exists():
+        shutil.copy(src / f"{probe}.txt", dst / f"{tag}_{name}.txt")
 
 traffic = {}
 for d in sorted(glob.glob(str(src / "pmc_*_SIZE"))):
