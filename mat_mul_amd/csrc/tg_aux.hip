@@ -199,62 +199,55 @@ __global__ __launch_bounds__(kBlock) void hash_kernel(const int8_t* state, uint6
 // ---------------------------------------------------------------------------------------------
 // N3: sum of slice ranks.  One wavefront per (game, slice i): lane r holds row r of the S x S
 // matrix state[b][i] reduced mod p; S elimination steps, each a ballot (pivot search), a broadcast
-// of the pivot row (readlane via shuffle) and a cross-multiplied update (no modular inverse):
+// of the pivot row (shuffle) and a cross-multiplied update (no modular inverse):
 // row_r <- row_r * piv_c - row_p * row_r[c]  (mod p).  Two primes, one per half-wave, ranks maxed.
+//
+// The arithmetic is done in DOUBLE PRECISION on balanced residues |x| <= p/2 with p < 2^26 (round 2; round 1 used
+// 31-bit primes and 64-bit integer products, ~26 integer instructions per element): t = a*pc - pk*mine is exact
+// (|t| < 2^51), q = rint(t / p) is off by less than 2^-24 before rounding, r = fma(-q, p, t) is exact and lands in
+// [-p/2, p/2] again -- five fp64 instructions per element, and CDNA4 issues v_fma_f64 at the rate of any other VOP3
+// (tools/issue_rate_probe.hip).  "Is this residue zero" is an exact comparison with 0.0.  A rank mod p can only be
+// too small, and is so with probability ~S/p per slice: both primes wrong on the same slice ~1e-13.
 // ---------------------------------------------------------------------------------------------
-// a*b mod P for P = 2^31 - C (C = 1 for the lower half-wave, 19 for the upper), a, b < P: 2^31 == C (mod P),
-// so the 62-bit product folds twice by shift-multiply-add instead of a 64-bit division.
-__device__ __forceinline__ uint32_t mulmod_half(uint32_t a, uint32_t b, bool upper, uint32_t P) {
-  uint64_t x = static_cast<uint64_t>(a) * b;  // < 2^62
-  uint64_t t = x >> 31;
-  x = (x & 0x7FFFFFFFull) + (upper ? (t << 4) + (t << 1) + t : t);  // < 2^31 + 2^31*C
-  t = x >> 31;
-  x = (x & 0x7FFFFFFFull) + (upper ? (t << 4) + (t << 1) + t : t);  // < 2^31 + C*C
-  uint32_t r = static_cast<uint32_t>(x);
-  if (r >= P) r -= P;
-  return r;
-}
-
-// Rank of one S x S slice modulo BOTH primes at once: lanes 0..31 eliminate mod 2^31 - 1, lanes 32..63 the
-// same matrix mod 2^31 - 19 (S <= 32 rows per half-wave); the halves choose their own pivots.  Returns the
-// larger of the two ranks (a rank mod p can only be too small).
+// Rank of one S x S slice modulo BOTH primes at once: lanes 0..31 eliminate mod 2^26 - 5, lanes 32..63 the
+// same matrix mod 2^26 - 27 (S <= 32 rows per half-wave); the halves choose their own pivots.  Returns the
+// larger of the two ranks.
 template <int ST>
 __device__ __forceinline__ int slice_rank2(const int8_t* m, int S, int lane) {
   constexpr int SMAX = ST ? ST : TG_MAX_S;
   const bool upper = lane >= 32;
   const int r0 = lane & 31;
-  const uint32_t P = upper ? 2147483629u : 2147483647u;
-  uint32_t row[SMAX];
+  const double P = upper ? 67108837.0 : 67108859.0;
+  const double invP = upper ? (1.0 / 67108837.0) : (1.0 / 67108859.0);
+  double row[SMAX];
 #pragma unroll
-  for (int c = 0; c < SMAX; ++c) {
-    int v = (r0 < S && c < S) ? m[r0 * S + c] : 0;
-    row[c] = v < 0 ? P - static_cast<uint32_t>(-v) : static_cast<uint32_t>(v);
-  }
+  for (int c = 0; c < SMAX; ++c) row[c] = (r0 < S && c < S) ? static_cast<double>(m[r0 * S + c]) : 0.0;
   bool used = r0 >= S;  // rows already chosen as pivots (and the idle lanes)
   int rank = 0;
 #pragma unroll
   for (int c = 0; c < SMAX; ++c) {
     if (c < S) {
-      const uint64_t cand = __ballot(!used && row[c] != 0);
+      const uint64_t cand = __ballot(!used && row[c] != 0.0);
       const uint32_t mine_half = upper ? static_cast<uint32_t>(cand >> 32) : static_cast<uint32_t>(cand);
       if (cand) {  // wave-uniform; a half without a candidate just idles through the step
         const bool has = mine_half != 0;
         const int pr = (upper ? 32 : 0) + (has ? __builtin_ctz(mine_half) : 0);  // this half's pivot row
-        const uint32_t pc = __shfl(row[c], pr);
-        const uint32_t mine = row[c];
-        const bool upd = has && !used && lane != pr && mine != 0;
+        const double pc = __shfl(row[c], pr);
+        const double mine = row[c];
+        const bool upd = has && !used && lane != pr && mine != 0.0;
         // columns < c of every unused row were zeroed by earlier pivots, and column c becomes zero
 #pragma unroll
         for (int k = c + 1; k < SMAX; ++k) {
           if (k < S) {
-            const uint32_t pk = __shfl(row[k], pr);
+            const double pk = __shfl(row[k], pr);
             if (upd) {
-              const uint32_t a = mulmod_half(row[k], pc, upper, P), b = mulmod_half(pk, mine, upper, P);
-              row[k] = a >= b ? a - b : a + P - b;
+              const double t = __builtin_fma(row[k], pc, -(pk * mine));
+              const double q = __builtin_rint(t * invP);
+              row[k] = __builtin_fma(-q, P, t);
             }
           }
         }
-        if (upd) row[c] = 0;
+        if (upd) row[c] = 0.0;
         if (has && lane == pr) used = true;
         rank += has;
       }

@@ -734,6 +734,17 @@ def test_slice_rank_golden_and_oracle(golden):
         st[0] = 0
         st[1, :, 1:] = st[1, :, :1]                                  # every slice has rank <= 1
         assert np.array_equal(host(ops.slice_rank(dev(st))), O.slice_rank_exact(st))
+    # rank-deficient slices with entries over the whole int8 range (the kernel eliminates modulo two 26-bit primes in
+    # double precision: huge minors, exact zeros required) against the exact fraction-free oracle
+    for S, B in [(25, 6), (16, 10), (9, 24), (5, 40)]:
+        st = np.zeros((B, S, S, S), np.int64)
+        for b in range(B):
+            for i in range(S):
+                for _ in range(int(rng.integers(0, 5))):                 # slice i = sum of up to 4 rank-1 matrices
+                    st[b, i] += np.outer(rng.integers(-6, 7, S), rng.integers(-6, 7, S))
+        st = np.clip(st, -128, 127).astype(np.int8)
+        st[0] = rng.integers(-128, 128, size=(S, S, S))                  # full rank, large entries
+        assert np.array_equal(host(ops.slice_rank(padded(st))), O.slice_rank_exact(st)), S
     env = TensorGameEnv(3, 4, DEV)
     env.reset()
     assert host(env.rank_reward()).tolist() == [-8, -8, -8]           # <2,2,2>: four slices of rank 2
