@@ -870,7 +870,9 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
 // A game with more than 64 candidate rows (dense factors) takes the direct form: all four chunks of every lane.
 // =============================================================================================
 // one chunk: x - (-uv) ... i.e. x + uvn * w, uvn = -u_i v_j; saturating int16 form, 32-bit redo when the range test fails
-__device__ __forceinline__ uint4 s16_chunk(const uint4& x, int uvn, const uint32_t (&wp)[8], const uint4& wq, int shift,
+// (wfetch: the game's 16 w tokens again, for the redo only -- keeping them would cost four registers on the common path)
+template <class WFetch>
+__device__ __forceinline__ uint4 s16_chunk(const uint4& x, int uvn, const uint32_t (&wp)[8], WFetch wfetch, int shift,
                                            bool wide_shift, uint32_t& cnz, uint32_t& ovf) {
   // Saturating int16 form, as in s4_step_slice: with |factor| <= 255 (int8 tokens, |shift| <= 127) the clamped u*v and
   // (u v) w + x are formed exactly or saturate, so everything the 16-bit form cannot represent ends outside int8 --
@@ -886,6 +888,7 @@ __device__ __forceinline__ uint4 s16_chunk(const uint4& x, int uvn, const uint32
   cnz = 0;
   uint4 res = pack_pairs(A, cnz, c16);
   if (__builtin_expect(wide_shift || (c16 & 0xFF00FF00u), 0)) {  // rare: exact 32-bit form of this chunk,
+    const uint4 wq = wfetch();
     const uint32_t wd[4] = {wq.x, wq.y, wq.z, wq.w};              // one dword at a time (the common path keeps <= 64 VGPRs:
     const uint32_t pd[4] = {x.x, x.y, x.z, x.w};                  // 8 wavefronts per SIMD, cfg3 resident in one round)
     uint32_t rd[4];
@@ -931,6 +934,7 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
               p2 = *reinterpret_cast<const uint4*>(src + 2048), p3 = *reinterpret_cast<const uint4*>(src + 3072);
   const uint4 uq = *reinterpret_cast<const uint4*>(tok);
   const uint4 wq = *reinterpret_cast<const uint4*>(tok + 32);
+  auto wfetch = [&]() { return *reinterpret_cast<const uint4*>(tok + 32); };
   const int vj = tok[16 + (lane & 15)] - a.shift;
   const int r = lane >> 4;
   uint32_t nz = 0, ovf = 0;
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
       const uint4 x = qd[wave][lane];
       const int2 me = qm[wave][lane];
       uint32_t cnz;
-      const uint4 res = s16_chunk(x, me.y, wp, wq, a.shift, wide_shift, cnz, ovf);
+      const uint4 res = s16_chunk(x, me.y, wp, wfetch, a.shift, wide_shift, cnz, ovf);
       nz |= cnz;
       if constexpr (LINES) {
         qd[wave][lane] = res;  // back to the owner, who stores whole lines
@@ -1009,7 +1013,7 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
       uint4 res = pn;
       if (uvn != 0) {
         uint32_t cnz;
-        res = s16_chunk(pn, uvn, wp, wq, a.shift, wide_shift, cnz, ovf);
+        res = s16_chunk(pn, uvn, wp, wfetch, a.shift, wide_shift, cnz, ovf);
         nz |= cnz;
       }
       const bool chg = differs(res, pn);
@@ -1035,22 +1039,32 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
 // rows the action changed (9 % with the reference's vocabulary) plus `done`: the launch-per-step kernel re-reads
 // 32 MiB per step at BASELINE config 3, this one moves ~3 MB.  8192 games = 32 wavefronts per CU on 256 CUs: all
 // resident at <= 64 VGPRs (__launch_bounds__(256, 8)).
+// With eight wavefronts per SIMD a step is bound by instruction issue, so -- as in s16_step_kernel -- the arithmetic is
+// done only on the rows the action touches: candidates go through the wavefront's 64-entry queue in LDS, one dense pass
+// computes and stores them, and the results return through the queue to the registers of their owners.
 // =============================================================================================
 __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int QCAP = 64;
+  __shared__ __attribute__((aligned(16))) uint4 qd[kBlock / 64][QCAP];
+  __shared__ __attribute__((aligned(8))) int2 qm[kBlock / 64][QCAP];
   const int lane = threadIdx.x & 63;
   // the game index is wave-uniform; say so (readfirstlane), or hipcc wraps every access through the per-game token
   // descriptor in a waterfall loop
-  const int64_t g = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave;
   if (g >= a.B) return;
   const int r = lane >> 4;
   const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.state, 0, static_cast<int>(a.B * a.stride), 0x00027000);
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(a.done, 0, 0x7fffffff, 0x00027000);
-  const int soff = static_cast<int>(g * a.stride) + 16 * lane;
-  uint4 par[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) par[n] = *reinterpret_cast<const uint4*>(a.state + g * a.stride + 16 * lane + 1024 * n);
+  const int soff = static_cast<int>(g * a.stride);
+  const int8_t* const src = a.state + g * a.stride + 16 * lane;
+  // (four named chunks, not an array: see s16_step_kernel)
+  uint4 p0 = *reinterpret_cast<const uint4*>(src), p1 = *reinterpret_cast<const uint4*>(src + 1024),
+        p2 = *reinterpret_cast<const uint4*>(src + 2048), p3 = *reinterpret_cast<const uint4*>(src + 3072);
   const uint32_t shp = (static_cast<uint32_t>(a.shift) & 0xFFFFu) | (static_cast<uint32_t>(a.shift) << 16);
+  const bool wide_shift = static_cast<unsigned>(a.shift + 127) > 254u;  // uniform; factors may exceed 255
+  auto differs = [](const uint4& x, const uint4& y) { return x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w; };
   for (int k = 0; k < a.K; ++k) {
     if (a.ready) {
       uint32_t spins = 0;
@@ -1066,50 +1080,88 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int8_t*>(a.actions + (static_cast<int64_t>(k) * a.B + g) * 48), 0, 48, 0x00027000);
     const u32x4 uq = __builtin_amdgcn_raw_buffer_load_b128(trs, 0, 0, 16);
-    const u32x4 wq = __builtin_amdgcn_raw_buffer_load_b128(trs, 32, 0, 16);
+    const u32x4 wqv = __builtin_amdgcn_raw_buffer_load_b128(trs, 32, 0, 16);
     const int vj = static_cast<int8_t>(__builtin_amdgcn_raw_buffer_load_b8(trs, 16 + (lane & 15), 0, 16)) - a.shift;
+    auto wfetch = [&]() {
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(trs, 32, 0, 16);
+      return uint4{t[0], t[1], t[2], t[3]};
+    };
+    uint32_t ovf = 0;
+    // ---- candidates -> queue ----
+    int total = 0;  // uniform
+    // (the slot of a lane's candidate is recomputed from the ballot when the result comes back: the ballots live in
+    // SGPRs, four slots would be four more VGPRs of the 64 this kernel may use)
+    auto slot_of = [&](unsigned long long m, int base) {
+      return base + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
+    };
+    auto enqueue = [&](int n, const uint4& pn, uint32_t udw, int& uvn) {
+      const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(udw), 8 * r, 8);  // -(u_i), i = r + 4 n
+      uvn = ui * vj;
+      const unsigned long long m = __ballot(uvn != 0);
+      const int slot = slot_of(m, total);
+      if (uvn != 0 && slot < QCAP) {
+        qd[wave][slot] = pn;
+        qm[wave][slot] = int2{lane + 64 * n, uvn};
+      }
+      total += __builtin_popcountll(m);
+      return m;
+    };
+    int uv0, uv1, uv2, uv3;
+    const unsigned long long m0 = enqueue(0, p0, uq[0], uv0);
+    const int b1 = total;
+    const unsigned long long m1 = enqueue(1, p1, uq[1], uv1);
+    const int b2 = total;
+    const unsigned long long m2 = enqueue(2, p2, uq[2], uv2);
+    const int b3 = total;
+    const unsigned long long m3 = enqueue(3, p3, uq[3], uv3);
     uint32_t wp[8];
-    unpack_pairs(uint4{wq[0], wq[1], wq[2], wq[3]}, wp);
+    unpack_pairs(uint4{wqv[0], wqv[1], wqv[2], wqv[3]}, wp);
 #pragma unroll
     for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
-    const uint32_t vjp = __builtin_amdgcn_perm(static_cast<uint32_t>(vj), static_cast<uint32_t>(vj), 0x05040100u);
-    uint32_t nz = 0, ovf = 0;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(uq[n]), 8 * r, 8);  // -(u_i), i = r + 4 n
-      const uint32_t uip = __builtin_amdgcn_perm(static_cast<uint32_t>(ui), static_cast<uint32_t>(ui), 0x05040100u);
-      const uint32_t pr = pk_mad_i16_sat(uip, vjp, 0u);
-      uint32_t A[8];
-      unpack_pairs(par[n], A);
-#pragma unroll
-      for (int p = 0; p < 8; ++p) A[p] = pk_mad_i16_sat(pr, wp[p], A[p]);
-      uint32_t cnz = 0, c16 = 0;
-      uint4 res = pack_pairs(A, cnz, c16);
-      if (__builtin_expect((c16 & 0xFF00FF00u) != 0, 0)) {  // rare: exact 32-bit form of this chunk (wrapped bytes + flag),
-        const int uv = ui * vj;                              // one dword at a time: the common path keeps 64 VGPRs
-        const uint32_t pd[4] = {par[n].x, par[n].y, par[n].z, par[n].w};
-        uint32_t rd[4];
-        int o32 = 0;
-        cnz = 0;
-#pragma unroll 1
-        for (int d = 0; d < 4; ++d) {
-          int e[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            e[t] = sbyte(pd[d], t) + uv * (sbyte(wq[d], t) - a.shift);
-            o32 |= e[t] + 128;
-          }
-          rd[d] = pack4(e[0], e[1], e[2], e[3]);
-          cnz |= rd[d];
+    // a changed row is written through at once (sc1: visible to other agents once this wavefront's vmcnt drains)
+    auto put = [&](const uint4& res, int c) {
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{res.x, res.y, res.z, res.w}, srs, soff + 16 * c, 0, 16);
+    };
+    // One round when the candidates fit the queue; otherwise (dense factors) four rounds, round n taking chunk n of
+    // every lane (at most 64 entries by construction) -- the same dense pass either way.
+    const int rounds = total <= QCAP ? 1 : 4;  // uniform
+    for (int rd = 0; rd < rounds; ++rd) {
+      int cnt = total;
+      if (rounds == 4) {
+        const unsigned long long m = rd == 0 ? m0 : (rd == 1 ? m1 : (rd == 2 ? m2 : m3));
+        const int uvn = rd == 0 ? uv0 : (rd == 1 ? uv1 : (rd == 2 ? uv2 : uv3));
+        const uint4 pn = rd == 0 ? p0 : (rd == 1 ? p1 : (rd == 2 ? p2 : p3));
+        __builtin_amdgcn_wave_barrier();
+        if (uvn != 0) {
+          const int slot = slot_of(m, 0);
+          qd[wave][slot] = pn;
+          qm[wave][slot] = int2{lane + 64 * rd, uvn};
         }
-        res = uint4{rd[0], rd[1], rd[2], rd[3]};
-        ovf |= static_cast<uint32_t>(o32) & ~255u;
+        cnt = __builtin_popcountll(m);
       }
-      nz |= cnz;
-      const bool same = res.x == par[n].x && res.y == par[n].y && res.z == par[n].z && res.w == par[n].w;
-      par[n] = res;
-      if (!same) __builtin_amdgcn_raw_buffer_store_b128(u32x4{res.x, res.y, res.z, res.w}, srs, soff + 1024 * n, 0, 16);
+      __builtin_amdgcn_wave_barrier();  // (LDS serves one wavefront's accesses in order)
+      if (lane < cnt) {
+        const uint4 x = qd[wave][lane];
+        const int2 me = qm[wave][lane];
+        uint32_t cnz;
+        const uint4 res = s16_chunk(x, me.y, wp, wfetch, a.shift, wide_shift, cnz, ovf);
+        if (differs(res, x)) put(res, me.x);
+        qd[wave][lane] = res;  // back to the owner's registers
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (rounds == 1) {
+        if (uv0 != 0) p0 = qd[wave][slot_of(m0, 0)];
+        if (uv1 != 0) p1 = qd[wave][slot_of(m1, b1)];
+        if (uv2 != 0) p2 = qd[wave][slot_of(m2, b2)];
+        if (uv3 != 0) p3 = qd[wave][slot_of(m3, b3)];
+      } else {
+        if (rd == 0 && uv0 != 0) p0 = qd[wave][slot_of(m0, 0)];
+        if (rd == 1 && uv1 != 0) p1 = qd[wave][slot_of(m1, 0)];
+        if (rd == 2 && uv2 != 0) p2 = qd[wave][slot_of(m2, 0)];
+        if (rd == 3 && uv3 != 0) p3 = qd[wave][slot_of(m3, 0)];
+      }
     }
+    const uint32_t nz = p0.x | p0.y | p0.z | p0.w | p1.x | p1.y | p1.z | p1.w | p2.x | p2.y | p2.z | p2.w | p3.x | p3.y | p3.z | p3.w;
     const bool any_nz = __ballot(nz != 0) != 0;
     if (lane == 0)
       __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(any_nz ? 0 : 1), drs,

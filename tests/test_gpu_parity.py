@@ -1169,6 +1169,7 @@ def test_step_stream_equals_k_single_steps(S, B, K):
         st[3] = 127
         ac[1, 3] = 0                                                       # factors -1: 127 - (-1) overflows at step 1
         ac[2, 2] = rng.integers(-3, 6, size=3 * S)                         # wide factors (int16 path limits)
+        ac[K - 1, 1::4] = rng.integers(0, 3, size=ac[K - 1, 1::4].shape)   # dense actions (S=16: more candidate rows than the queue holds)
     want_done, want_ovf, cur = np.zeros((K, B), np.uint8), np.zeros(B, np.uint8), st.copy()
     for k in range(K):
         cur, d, o = O.step_i8(cur, ac[k])
