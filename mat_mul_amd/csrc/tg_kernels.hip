@@ -922,7 +922,8 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
   constexpr int QCAP = 64;  // queue entries per wavefront
   __shared__ __attribute__((aligned(16))) uint4 qd[kBlock / 64][QCAP];  // the candidate chunks
   __shared__ __attribute__((aligned(8))) int2 qm[kBlock / 64][QCAP];    // (chunk index, -u_i v_j)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wavefront index is uniform; saying so lets the game's tokens come by scalar loads)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   int64_t g = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave;
   const bool live = g < a.B;
   if (!live) g = a.B - 1;
