@@ -53,7 +53,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 INFINITY_CACHE_BYTES = 256 << 20
-STEP_KERNEL = {4: "tg::s4_kernel<0>", 9: "tg::packed_kernel<9, 16, 0>", 25: "tg::s25_step_kernel"}
+STEP_KERNEL = {4: "tg::s4_kernel<0>", 9: "tg::s9_step_kernel", 25: "tg::s25_step_kernel"}
 
 
 def step_kernel_name(S: int, B: int) -> str:

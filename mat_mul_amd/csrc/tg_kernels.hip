@@ -1524,6 +1524,16 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     }
   }
   const bool no_s25 = TG_SWITCH("TG_NO_S25_DIRECT");  // A/B switch for measurements
+  const bool no_s9 = TG_SWITCH("TG_NO_S9_DIRECT");    // A/B switch for measurements
+  if constexpr (MODE == STEP) {
+    if (al && a.S == 9 && a.shift >= -127 && a.shift <= 127 && !force_i32 && !no_s9) {
+      const int64_t blocks = (B + 15) / 16;  // four wavefronts of four games
+      if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
+      (void)hipGetLastError();
+      hipLaunchKernelGGL(s9_step_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+      return check_launch(fn);
+    }
+  }
   if constexpr (MODE == STEP) {
     // (|shift| <= 127: factors within +-255, which the 32-bit redo of s25_step_kernel takes from its int16 tables)
     if (al && a.S == 25 && a.shift >= -127 && a.shift <= 127 && B <= 0x7fffffffLL && !force_i32 && !no_s25) {

@@ -773,3 +773,223 @@ __global__ __launch_bounds__(kBlock, 7) void s25_step_kernel(ApplyArgs a) {  // 
     if (a.overflow && (both & 2u)) a.overflow[g] = 1;
   }
 }
+
+
+// =============================================================================================
+// S = 9 single step (3x3 matrix multiplication), wavefront-local: four games per wavefront, a team of 16 lanes per
+// game, ALL 16 lanes busy (chunks lt, lt + 16, lt + 32 of the game's 46; packed_kernel<9, 16> keeps 9 of 16 lanes busy
+// with 6 chunks each for its period trick, stages through LDS with workgroup barriers and scans the tokens first).
+// No workgroup barrier at all: a team's int16 table (packed_kernel's: -u, 0, v, pad, two periodic copies of w) is
+// written and read by its own wavefront, and LDS serves one wavefront's accesses in order.
+// Arithmetic only where the action acts (see s16_step_kernel): a chunk touches up to three rows (i, j); it is a
+// candidate when one of them has u_i v_j != 0 (~23 %).  Candidates of the wavefront's four games go through one
+// 64-entry queue; in the dense pass a lane reads the window of ITS entry (team table + the chunk's position in the
+// row), splits it at the two row boundaries with masks from a small table ("elements below h"), does the
+// saturating int16 multiply-adds (32-bit redo when the range test fails: exact or flagged, as everywhere), stores.
+// done / overflow per game: ballots -- the owners' over the unchanged chunks, the dense lanes' per team.
+// =============================================================================================
+__global__ __launch_bounds__(kBlock, 6) void s9_step_kernel(ApplyArgs a) {  // (14 spills at 64 VGPRs)
+  constexpr int S = 9, TS = 16;
+  using G = PGeo<S, TS>;  // (UVLEN, WE, FSTRIDE, NCHUNK, TAIL as in packed_kernel<9, 16>)
+  static_assert(G::FSTRIDE <= 5 * TS && G::NCHUNK <= 3 * TS && G::TAIL == 9, "s9_step_kernel geometry");
+  constexpr int QCAP = 64, GPW = 64 / TS, NWAVE = kBlock / 64;
+  __shared__ __attribute__((aligned(16))) short F[NWAVE * GPW][G::FSTRIDE];
+  __shared__ __attribute__((aligned(16))) uint4 qd[NWAVE][QCAP];
+  __shared__ __attribute__((aligned(16))) int4 qm[NWAVE][QCAP];   // (chunk | team << 8, uv of the three rows)
+  __shared__ __attribute__((aligned(16))) uint32_t below[17][8];  // below[h][p]: int16-pair mask of window elements k < h
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = lane >> 4, lt = lane & 15;
+  int64_t g = (static_cast<int64_t>(blockIdx.x) * NWAVE + wave) * GPW + team;
+  const bool live = g < a.B;
+  if (!live) g = a.B - 1;
+  const int8_t* const tok = a.actions + g * (3 * S);
+  const int8_t* const in = a.in + g * a.in_stride;
+  int8_t* const out = a.out + g * a.out_stride;
+  short* const Fg = F[wave * GPW + team];
+  // ---- loads: the lane's table entries (tokens) first, then its three chunks ----
+  int tv[5], sidx[5];
+#pragma unroll
+  for (int e = 0; e < 5; ++e) {
+    const int pos = lt + TS * e;
+    int si = -1;
+    if (pos < S) {
+      si = pos;                                   // u (stored negated)
+    } else if (pos > S && pos <= 2 * S) {
+      si = S + (pos - S - 1);                     // v
+    } else if (pos >= G::UVLEN && pos < G::FSTRIDE) {
+      int q = pos - G::UVLEN;
+      const int copy = q >= G::WE;
+      q -= copy * G::WE;
+      si = 2 * S + (q + copy) % S;                // periodic copies of w (copy 1 shifted by one)
+    }
+    sidx[e] = si;
+    tv[e] = tok[si >= 0 ? si : 0];
+  }
+  // whole 16-byte chunks; the last chunk's bytes past S^3 = 729 lie inside the game's stride (736) except, possibly,
+  // for the LAST game of the batch, which takes load_chunk's byte-wise tail
+  const bool last_game = g == a.B - 1;
+  auto load = [&](int c) {
+    uint4 q = uint4{0, 0, 0, 0};
+    if (c < G::NCHUNK) q = (c == G::NCHUNK - 1 && last_game) ? load_chunk<G::TAIL>(in + 16 * c, true) : *reinterpret_cast<const uint4*>(in + 16 * c);
+    return q;
+  };
+  uint4 p0 = load(lt), p1 = load(lt + TS), p2 = load(lt + 2 * TS);
+  if (lt + 2 * TS == G::NCHUNK - 1) {  // the tail chunk: only 9 bytes belong to the game
+    p2.z &= 0x000000FFu;
+    p2.w = 0;
+  }
+  for (int e = tid; e < 17 * 8; e += kBlock) {
+    const int h = e >> 3, p = e & 7;
+    below[h][p] = ((2 * p < h) ? 0x0000FFFFu : 0u) | ((2 * p + 1 < h) ? 0xFFFF0000u : 0u);
+  }
+#pragma unroll
+  for (int e = 0; e < 5; ++e) {
+    const int pos = lt + TS * e;
+    if (pos < G::FSTRIDE) {
+      int val = sidx[e] >= 0 ? tv[e] - a.shift : 0;
+      if (pos < S) val = -val;
+      Fg[pos] = static_cast<short>(val);
+    }
+  }
+  __syncthreads();  // (only for `below`, written once per workgroup; the tables are wavefront-local)
+  const bool inplace = a.in == a.out;
+  uint32_t nz = 0, ovf = 0;
+  auto differs = [](const uint4& x, const uint4& y) { return x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w; };
+
+  // ---- which chunks does the action touch?  candidates -> the wavefront's queue ----
+  int total = 0;  // uniform
+  auto enqueue = [&](int n, const uint4& pn, int (&uv)[3]) -> unsigned long long {
+    const int c = lt + TS * n;
+    const bool cv = c < G::NCHUNK;
+    const int r0 = (16 * c) / S, l0 = (16 * c) % S;
+#pragma unroll
+    for (int sgm = 0; sgm < 3; ++sgm) {
+      const int row = r0 + sgm;
+      int i = row / S;
+      const int j = row - i * S;
+      if (!cv || i >= S) i = S;  // Fg[S] == 0: rows past the tensor (and idle chunks) add nothing
+      uv[sgm] = mul24_pinned(Fg[i], Fg[S + 1 + j]);
+    }
+    if (l0 + 16 <= 2 * S) uv[2] = 0;  // the window does not reach a third row
+    const bool cand = (uv[0] | uv[1] | uv[2]) != 0;
+    const unsigned long long m = __ballot(cand);
+    const int slot = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
+    if (cand) {
+      if (slot < QCAP) {
+        qd[wave][slot] = pn;
+        qm[wave][slot] = int4{c | (team << 8), uv[0], uv[1], uv[2]};
+      }
+    } else {
+      nz |= pn.x | pn.y | pn.z | pn.w;
+      if (!inplace && cv && live) store_chunk<G::TAIL>(out + 16 * c, pn, c == G::NCHUNK - 1);
+    }
+    total += __builtin_popcountll(m);
+    return m;
+  };
+  int uva[3], uvb[3], uvc[3];
+  const unsigned long long ma = enqueue(0, p0, uva);
+  const unsigned long long mb = enqueue(1, p1, uvb);
+  const unsigned long long mc = enqueue(2, p2, uvc);
+
+  // one chunk: x + (uv of its row) * w over the window at the chunk's position, table Ft, game base ot
+  uint32_t dnz = 0;
+  auto finish = [&](const uint4& x, int c, const short* Ft, int8_t* ot, bool lv, int u0, int u1, int u2) {
+    const int l0 = (16 * c) % S, h0 = S - l0, h1 = 2 * S - l0;  // elements k < h0: first row; h0 <= k < h1: second
+    const uint32_t* wp = reinterpret_cast<const uint32_t*>(Ft + G::UVLEN + (l0 & 1) * G::WE + (l0 & ~1));
+    const uint32_t* m0 = below[h0];
+    const uint32_t* m1 = below[h1 < 16 ? h1 : 16];
+    const int c0 = max(-32767, min(32767, u0)), c1 = max(-32767, min(32767, u1)), c2 = max(-32767, min(32767, u2));
+    const uint32_t q0 = __builtin_amdgcn_perm(static_cast<uint32_t>(c0), static_cast<uint32_t>(c0), 0x05040100u);
+    const uint32_t q1 = __builtin_amdgcn_perm(static_cast<uint32_t>(c1), static_cast<uint32_t>(c1), 0x05040100u);
+    const uint32_t q2 = __builtin_amdgcn_perm(static_cast<uint32_t>(c2), static_cast<uint32_t>(c2), 0x05040100u);
+    uint32_t A[8], wraw[8];
+    unpack_pairs(x, A);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      wraw[p] = wp[p];
+      const uint32_t w0 = wraw[p] & m0[p], t1 = wraw[p] & m1[p];
+      A[p] = pk_mad_i16_sat(q0, w0, A[p]);
+      A[p] = pk_mad_i16_sat(q1, t1 ^ w0, A[p]);
+      A[p] = pk_mad_i16_sat(q2, wraw[p] ^ t1, A[p]);
+    }
+    uint32_t c16 = 0, cnz = 0;
+    uint4 res = pack_pairs(A, cnz, c16);
+    if (__builtin_expect((c16 & 0xFF00FF00u) != 0, 0)) {  // rare: the chunk again in 32 bits (wrapped bytes + flag)
+      const uint32_t pd[4] = {x.x, x.y, x.z, x.w};
+      uint32_t rd[4];
+      int o32 = 0;
+      cnz = 0;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        int e[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int k = 4 * d + t;
+          const int w = static_cast<short>(wraw[k >> 1] >> (16 * (k & 1)));
+          e[t] = sbyte(pd[d], t) + (k < h0 ? u0 : (k < h1 ? u1 : u2)) * w;
+          o32 |= e[t] + 128;
+        }
+        rd[d] = pack4(e[0], e[1], e[2], e[3]);
+        cnz |= rd[d];
+      }
+      res = uint4{rd[0], rd[1], rd[2], rd[3]};
+      ovf |= static_cast<uint32_t>(o32) & ~255u;
+    }
+    // (the tail chunk needs no care here: its bytes past the tensor are zero on entry and belong to rows i >= S,
+    // whose product is the table's zero entry, so they stay zero; store_chunk writes its 9 bytes)
+    dnz |= cnz;
+    if (lv && (!inplace || differs(res, x))) store_chunk<G::TAIL>(ot + 16 * c, res, c == G::NCHUNK - 1);
+  };
+  // One round when the candidates fit the queue; otherwise (dense factors) three rounds, round n taking chunk n of
+  // every lane (at most 64 entries by construction) -- the same dense pass either way.  A lane may finish chunks of
+  // different games in different rounds: their non-zero / overflow bits are kept per team.
+  uint32_t dnz_t = 0, ovf_t = 0;  // bit t: a chunk of team t finished by this lane is non-zero / overflowed
+  const int rounds = total <= QCAP ? 1 : 3;  // uniform
+  for (int rd = 0; rd < rounds; ++rd) {
+    int cnt = total;
+    if (rounds == 3) {
+      const unsigned long long m = rd == 0 ? ma : (rd == 1 ? mb : mc);
+      const uint4 pn = rd == 0 ? p0 : (rd == 1 ? p1 : p2);
+      const int u0 = rd == 0 ? uva[0] : (rd == 1 ? uvb[0] : uvc[0]), u1 = rd == 0 ? uva[1] : (rd == 1 ? uvb[1] : uvc[1]),
+                u2 = rd == 0 ? uva[2] : (rd == 1 ? uvb[2] : uvc[2]);
+      __builtin_amdgcn_wave_barrier();
+      if ((u0 | u1 | u2) != 0) {
+        const int slot = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
+        qd[wave][slot] = pn;
+        qm[wave][slot] = int4{(lt + TS * rd) | (team << 8), u0, u1, u2};
+      }
+      cnt = __builtin_popcountll(m);
+    }
+    __builtin_amdgcn_wave_barrier();  // (LDS serves one wavefront's accesses in order)
+    if (lane < cnt) {
+      const uint4 x = qd[wave][lane];
+      const int4 me = qm[wave][lane];
+      const int dteam = me.x >> 8;
+      const int64_t gd = (static_cast<int64_t>(blockIdx.x) * NWAVE + wave) * GPW + dteam;
+      dnz = 0;
+      const uint32_t ovf_before = ovf;
+      ovf = 0;
+      finish(x, me.x & 255, F[wave * GPW + dteam], a.out + (gd < a.B ? gd : a.B - 1) * a.out_stride, gd < a.B, me.y, me.z, me.w);
+      if (dnz) dnz_t |= 1u << dteam;
+      if (ovf) ovf_t |= 1u << dteam;
+      ovf = ovf_before;
+    }
+  }
+  // ---- done / overflow per game: the owners' ballot over the unchanged chunks (team = 16-lane slice) and the
+  // finishing lanes' per-team bits ----
+  const unsigned long long own = __ballot(nz != 0);
+  bool any_nz = ((own >> (16 * team)) & 0xFFFFull) != 0, any_ovf = false;
+#pragma unroll
+  for (int t = 0; t < GPW; ++t) {
+    const bool tnz = __ballot((dnz_t >> t) & 1u) != 0, tov = __ballot((ovf_t >> t) & 1u) != 0;
+    if (t == team) {
+      any_nz = any_nz || tnz;
+      any_ovf = tov;
+    }
+  }
+  if (lt == 0 && live) {
+    a.done[g] = any_nz ? 0 : 1;
+    if (a.overflow && any_ovf) a.overflow[g] = 1;
+  }
+}

@@ -76,8 +76,8 @@ for d in sorted(glob.glob(str(src / "pmc_*_SIZE"))):
     vals, durs = collections.defaultdict(list), collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        # the STEP kernels: s4_kernel<0>, packed_kernel<S, TS, 0>, s16_step_kernel<0, LINES>, s25_step_kernel
-        if "tg::" in n and ("<0>" in n or ", 0>" in n or "<0, " in n or "s25_step_kernel" in n) and "copy" not in n:
+        # the STEP kernels: s4_kernel<0>, packed_kernel<S, TS, 0>, s16_step_kernel<0, LINES>, s25_step_kernel, s9_step_kernel
+        if "tg::" in n and ("<0>" in n or ", 0>" in n or "<0, " in n or "s25_step_kernel" in n or "s9_step_kernel" in n) and "copy" not in n:
             vals[n].append(float(r["Counter_Value"]))
             durs[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for n, v in vals.items():

@@ -104,7 +104,7 @@ dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 host = lambda t: t.detach().cpu().numpy()
 def padded(st):
     t = ops.alloc_states(st.shape[0], st.shape[1], DEV); t.copy_(torch.from_numpy(np.ascontiguousarray(st))); return t
-for S, B in [(16, 1), (16, 3), (16, 131), (25, 2), (25, 37)]:
+for S, B in [(16, 1), (16, 3), (16, 131), (25, 2), (25, 37), (9, 1), (9, 70)]:
     rng = np.random.default_rng(S * 7 + B)
     for case in ("sparse", "dense", "wide", "overflow", "null"):
         st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
@@ -146,10 +146,10 @@ def test_ab_switch_paths_stay_exact(env_name, tmp_path):
     _run(AB_SCRIPT, tmp_path, "AB_OK", {env_name: "1"})
 
 
-@pytest.mark.parametrize("env_name", ["TG_S16_LINES", "TG_NO_S25_DIRECT", "TG_NO_S16_DIRECT"])
+@pytest.mark.parametrize("env_name", ["TG_S16_LINES", "TG_NO_S25_DIRECT", "TG_NO_S16_DIRECT", "TG_NO_S9_DIRECT"])
 def test_single_step_variants_stay_exact(env_name, tmp_path):
     """The S=16 step with whole-line stores (the product takes it from 96 MiB of states on; forced here at small
-    batches), and the staged kernels that the direct S=16 / S=25 step kernels replaced: sparse, dense (more candidate
+    batches), and the staged kernels that the direct S=9 / S=16 / S=25 step kernels replaced: sparse, dense (more candidate
     rows than the queue holds), wide-factor, overflowing and null actions, in place and out of place."""
     _run(STEP_SCRIPT, tmp_path, "STEP_OK", {env_name: "1"})
 

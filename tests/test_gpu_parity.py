@@ -173,13 +173,13 @@ def test_step_matches_oracle(S, B):
     assert want_done.sum() >= 1
 
 
-@pytest.mark.parametrize("S,B", [(16, 1), (16, 130), (25, 1), (25, 21), (16, 24576)])
+@pytest.mark.parametrize("S,B", [(16, 1), (16, 130), (25, 1), (25, 21), (16, 24576), (9, 1), (9, 3), (9, 67), (9, 4099)])
 def test_step_direct_kernels_sparse_dense_null_actions(S, B):
-    """The direct S=16 / S=25 step kernels: sparse actions (S=16: the compacted queue), dense ones (more candidate rows
+    """The direct S=9 / S=16 / S=25 step kernels: sparse actions (S=16: the compacted queue), dense ones (more candidate rows
     than the queue holds: every chunk by its own lane), null actions, finished games; in place and out of place.
     B = 24 576 at S=16 is 96 MiB of states: the variant that stores whole 128-byte lines."""
     rng = np.random.default_rng(S * 31 + B)
-    for case in (("sparse", "dense", "null") if B < 1000 else ("sparse",)):
+    for case in (("sparse", "dense", "null") if B < 5000 else ("sparse",)):
         st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
         ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)).astype(np.int8)
         if case == "dense":
@@ -187,7 +187,7 @@ def test_step_direct_kernels_sparse_dense_null_actions(S, B):
         if case == "null":
             ac[:, :S] = 1
             st[::2] = 0
-        if B >= 1000:  # a few dense and a few finishing games inside the big batch
+        if B >= 5000:  # a few dense and a few finishing games inside the big batch
             ac[::97] = rng.integers(0, 3, size=ac[::97].shape)
             st[5::101] = O.gen_from_factors_i8(ac[5::101, None, :])[0]
         want, want_done, want_ovf = O.step_i8(st, ac)
@@ -200,7 +200,7 @@ def test_step_direct_kernels_sparse_dense_null_actions(S, B):
             assert np.array_equal(host(done), want_done) and not host(ovf).any(), (S, B, case, inplace)
             assert inplace or np.array_equal(host(t), st)
         assert case != "null" or want_done[::2].all()
-        assert B < 1000 or want_done[5::101].all()
+        assert B < 5000 or want_done[5::101].all()
 
 
 @pytest.mark.parametrize("S", [4, 9, 16, 25, 6])
