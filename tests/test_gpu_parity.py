@@ -249,7 +249,7 @@ def test_step_extreme_factors_full_int8_range(S):
             assert not want_ovf[0::4].any() and want_ovf.any()
 
 
-@pytest.mark.parametrize("S,K", [(25, 12), (25, 40), (25, 64), (25, 127), (16, 40), (16, 64), (16, 100), (9, 48), (9, 90)])
+@pytest.mark.parametrize("S,K", [(25, 6), (25, 12), (25, 40), (25, 64), (25, 127), (16, 40), (16, 64), (16, 100), (9, 48), (9, 90)])
 def test_step_many_matrix_core_path_verdicts(S, K):
     """tg_mfma.h many_mfma_kernel certifies a game only when its overflow bound holds and the zero state is
     reached at the last step or never; everything else goes to the lattice kernels through done_step.  One
