@@ -1475,6 +1475,11 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     //  verdict -- the lattice kernels 51.8 / 59.9 us at K = 4 / 8; S=16: 58-61 us against 24 / 42 / 57 / 65 at K = 8 / 20 / 32 / 40)
     if (al && a.nact <= 256 && !force_i32 && !no_mfma && (a.S == 9 || a.S == 16 || a.S == 25) && (pays || many_always)) {
       const int Rp = (a.nact + 31) & ~31;
+#ifdef TG_AB_SWITCHES
+#define TG_MANY_SET_ABLATE(a) ((a).only_flagged = getenv("TG_MANY_ABLATE") ? atoi(getenv("TG_MANY_ABLATE")) : 0)
+#else
+#define TG_MANY_SET_ABLATE(a) ((void)0)
+#endif
 #define TG_MANY_K(S_, KS_)                                                                       \
   do {                                                                                           \
     const int ldsb = many_mfma_lds_bytes<S_>(Rp);                                                \
@@ -1483,7 +1488,9 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     const int64_t per_wg = (B + resident - 1) / resident;                                        \
     const int64_t grid = (B + per_wg - 1) / per_wg;                                              \
     (void)hipGetLastError();                                                                     \
+    TG_MANY_SET_ABLATE(a);                                                                       \
     hipLaunchKernelGGL((many_mfma_kernel<S_, KS_>), dim3((unsigned)grid), dim3(kBlock), ldsb, st, a, Rp); \
+    a.only_flagged = 0;                                                                          \
     if (int rc = check_launch(fn)) return rc;                                                    \
   } while (0)
 #define TG_MANY(S_)                                                                              \

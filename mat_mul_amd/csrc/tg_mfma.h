@@ -359,14 +359,15 @@ __device__ __forceinline__ uint32_t abs4_i8(uint32_t x) {
 
 // Diagnostic build only (-DTG_STAMPS, tools/stamp_many.py): workgroups 0, 64, .., 960 record the shader clock (s_memtime,
 // 2.4 GHz) at phase boundaries into the OVERFLOW buffer (32 uint64 per workgroup; B >= 4096), which this kernel never
-// writes otherwise; slots 0 and 31 hold s_memrealtime (100 MHz, one counter for the whole chip) at entry and exit.
+// writes otherwise; slot 0 = kernel entry, slot 1 = set-up done, slot 31 = s_memrealtime (100 MHz, one counter for the whole
+// chip) at exit.
 #ifdef TG_STAMPS
 #define TG_MSTAMP(i)                                                                                        \
   do {                                                                                                      \
     const int tg_stamp_i = (i);                                                                             \
     if ((blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 16 && threadIdx.x == 0 && tg_stamp_i < 32 && a.overflow) \
       reinterpret_cast<unsigned long long*>(a.overflow)[(blockIdx.x >> 6) * 32 + tg_stamp_i] =              \
-          (tg_stamp_i == 0 || tg_stamp_i == 31) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+          tg_stamp_i == 31 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define TG_MSTAMP(i) \
@@ -378,7 +379,16 @@ template <int S, int KS>
 __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int Rp) {
   using G = MGeo<S>;
   static_assert((S % 8) < 3, "the two functional rows S, S+1 must be rows of the lower half-wave");
+#ifdef TG_AB_SWITCHES
+  const int ablate = a.only_flagged;  // A/B build only (TG_MANY_ABLATE, tools/ablate_many.py): 1 no token staging, 2 no state load,
+#define TG_MANY_ON(bit) (!(ablate & (bit)))  //  4 no action scalars, 8 no tiles, 16 no verdict scan, 32 no stores -- timing only
+#define TG_MANY_ABLATED (ablate != 0)        //  (an ablated run hands nothing over: the verdicts are meaningless)
+#else
+#define TG_MANY_ON(bit) true
+#define TG_MANY_ABLATED false
+#endif
   extern __shared__ __attribute__((aligned(16))) uint8_t mfma_smem[];
+  TG_MSTAMP(0);  // kernel entry
   if constexpr (KS != 0) Rp = 32 * KS;
   const int RS = Rp + 16;
   int8_t* const T = reinterpret_cast<int8_t*>(mfma_smem);
@@ -393,12 +403,20 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
   const int R = a.nact;
 
   for (int e = tid; e < (32 - S) * RS; e += kBlock) T[(3 * S) * RS + e] = 0;
+  // The functional weights come to LDS first (one coalesced load + a barrier): per-lane lookups in the __constant__
+  // table are vector loads, and the set-up chained four of their latencies (3.9 us per workgroup of four games).
+  int* const wl = reinterpret_cast<int*>(Tabs);  // set-up only: [2][2][32] uv weights, then [2][32] w weights
+  constexpr int kWL = sizeof(FunctionalWeights) / sizeof(int);
+  static_assert(kWL == 192 && kWL <= kBlock, "one weight per thread");
+  if (tid < kWL) wl[tid] = (&g_fw.uv[0][0][0])[tid];
+  __syncthreads();
+  auto wuv = [&](int m, int x, int i) { return wl[(m * 2 + x) * 32 + i]; };
+  auto ww = [&](int m, int i) { return wl[128 + m * 32 + i]; };
   for (int n = tid; n < G::NT * 32; n += kBlock) {
     const int nn = n < G::S2 ? n : G::S2 - 1;
     const int i = nn / S, j = nn - i * S;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-      cw[m * G::NT * 32 + n] = n < G::S2 ? static_cast<uint32_t>(g_fw.uv[m][0][i] * g_fw.uv[m][1][j]) : 0u;
+    for (int m = 0; m < 2; ++m) cw[m * G::NT * 32 + n] = n < G::S2 ? static_cast<uint32_t>(wuv(m, 0, i) * wuv(m, 1, j)) : 0u;
   }
 
   constexpr int NRG = kBlock / G::A3;
@@ -428,7 +446,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
     for (int t = 0; t < 4; ++t) {
       const int k = 16 * h + 4 * d + t;
       int v = 0;
-      if (k < S) v = col < S ? (k == col) : (col == S ? g_fw.w[0][k] : (col == S + 1 ? g_fw.w[1][k] : 0));
+      if (k < S) v = col < S ? (k == col) : (col == S ? ww(0, k) : (col == S + 1 ? ww(1, k) : 0));
       w |= static_cast<uint32_t>(v & 255) << (8 * t);
     }
     ida[d] = static_cast<int>(w);
@@ -442,15 +460,14 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
   int orpar = 0;
   int stamp = 2;
   (void)stamp;
-  TG_MSTAMP(0);
   __syncthreads();
-  TG_MSTAMP(1);
+  TG_MSTAMP(1);  // set-up done
   for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
     // ---- 1. factors (u negated: the products are subtracted), transposed into LDS; X0 into the image ----
     const __amdgpu_buffer_rsrc_t tok = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int8_t*>(a.actions + g * R * G::A3), 0, R * G::A3, 0x00027000);
     int big = 0;
-    if (srg < NRG) {
+    if (srg < NRG && TG_MANY_ON(1)) {
       for (int rb = 4 * srg; rb < Rp; rb += 4 * NRG * TB) {
         int f[TB][4];
 #pragma unroll
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
         }
       }
     }
-    {
+    if (TG_MANY_ON(2)) {
       const int8_t* src = a.in + g * a.in_stride;
       for (int c = tid; c < G::NCHUNK; c += kBlock)
         *reinterpret_cast<uint4*>(img + 16 * c) = load_chunk<G::TAIL>(src + 16 * c, c == G::NCHUNK - 1);
@@ -487,7 +504,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
     TG_MSTAMP(stamp++);  // staged (own part)
     __syncthreads();
     TG_MSTAMP(stamp++);  // B1 passed
-    const bool anybig = red[4 + orpar] != 0;
+    const bool anybig = red[4 + orpar] != 0 && !TG_MANY_ABLATED;
     if (tid == 0) red[4 + (orpar ^ 1)] = 0;
     orpar ^= 1;
     if (anybig) {  // factors beyond the byte products: the lattice kernels take this game
@@ -500,7 +517,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
     }
 
     // ---- 2a. per-action scalars: wavefront x < 3 takes factor vector x of every action ----
-    if (wave < 3) {
+    if (wave < 3 && TG_MANY_ON(4)) {
       const int uw = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: the weights come by scalar loads
       const int* wu0 = uw == 2 ? g_fw.w[0] : g_fw.uv[0][uw];
       const int* wu1 = uw == 2 ? g_fw.w[1] : g_fw.uv[1][uw];
@@ -531,7 +548,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       bound += static_cast<int>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_scan(static_cast<uint32_t>(pb))), 63));
       if (bound > (1 << 24)) bound = 1 << 24;
     }
-    const bool wide = bound > 127;  // workgroup-uniform: the scalar bound cannot certify this game
+    const bool wide = bound > 127 && !TG_MANY_ABLATED;  // workgroup-uniform: the scalar bound cannot certify this game
     TG_MSTAMP(stamp++);  // barrier + scalar bound
     if (wide) {
       // ---- elementwise bound: Bnd = |X0| + sum_r |u_r| (x) |v_r| (x) |w_r|, the same tiles on absolute values ----
@@ -648,6 +665,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
 #pragma unroll
     for (int k = 0; k < TPW; k += 2) {
       if (G::NT % NW != 0 && wave + NW * k >= G::NT) break;
+      if (!TG_MANY_ON(8)) break;
       __builtin_amdgcn_sched_barrier(0);
       uint32_t XA[4], XB[4] = {0, 0, 0, 0};
       tile(k, XA);
@@ -697,7 +715,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       const int maxfinal = red[2];
       uint32_t carry0 = 0, carry1 = 0;
       int first = -1;
-      for (int r0 = 0; r0 < Rp; r0 += 64) {
+      for (int r0 = 0; r0 < Rp && TG_MANY_ON(16); r0 += 64) {
         const int r = r0 + lane;
         uint32_t g0 = 0, g1 = 0;
         if (r < R) {
@@ -717,8 +735,9 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       redo |= first >= 0 && first < R - 1;                     // a candidate that the final state cannot confirm
       redo |= final_zero && first != R - 1;                    // cannot happen; never trust it silently
       dstep = (first == R - 1 && final_zero) ? R - 1 : -1;
+      if (TG_MANY_ABLATED) redo = false;
     }
-    if (!redo) {
+    if (!redo && TG_MANY_ON(32)) {
       int8_t* out = a.out + g * a.out_stride;
       for (int c = tid; c < G::NCHUNK; c += kBlock)
         store_chunk<G::TAIL>(out + 16 * c, *reinterpret_cast<const uint4*>(img + 16 * c), c == G::NCHUNK - 1);
