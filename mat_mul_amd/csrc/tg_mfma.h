@@ -362,11 +362,18 @@ __device__ __forceinline__ uint32_t abs4_i8(uint32_t x) {
 // writes otherwise; slot 0 = kernel entry, slot 1 = set-up done, slot 31 = s_memrealtime (100 MHz, one counter for the whole
 // chip) at exit.
 #ifdef TG_STAMPS
+// which workgroups record: 16 of them -- every 64th (one XCD, four CUs), or with -DTG_STAMPS_XCD the first of each XCD and
+// the 33rd (workgroup b runs on XCD b % 8)
+#ifdef TG_STAMPS_XCD
+#define TG_MSTAMP_SEL(b) ((b) < 8 ? (int)(b) : (((b) >= 256 + 0 && (b) < 256 + 8) ? (int)((b) - 256 + 8) : -1))
+#else
+#define TG_MSTAMP_SEL(b) ((((b) & 63) == 0 && ((b) >> 6) < 16) ? (int)((b) >> 6) : -1)
+#endif
 #define TG_MSTAMP(i)                                                                                        \
   do {                                                                                                      \
     const int tg_stamp_i = (i);                                                                             \
-    if ((blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 16 && threadIdx.x == 0 && tg_stamp_i < 32 && a.overflow) \
-      reinterpret_cast<unsigned long long*>(a.overflow)[(blockIdx.x >> 6) * 32 + tg_stamp_i] =              \
+    if (TG_MSTAMP_SEL(blockIdx.x) >= 0 && threadIdx.x == 0 && tg_stamp_i < 32 && a.overflow) \
+      reinterpret_cast<unsigned long long*>(a.overflow)[TG_MSTAMP_SEL(blockIdx.x) * 32 + tg_stamp_i] =              \
           tg_stamp_i == 31 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
