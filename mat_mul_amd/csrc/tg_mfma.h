@@ -603,7 +603,13 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
         }
       }
       if (m128) bmax = 128;
-      if (bmax) atomicMax(&red[3], bmax);
+      bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x111, 0xf, 0xf, false));
+      bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x112, 0xf, 0xf, false));
+      bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x114, 0xf, 0xf, false));
+      bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x118, 0xf, 0xf, false));
+      bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x142, 0xa, 0xf, false));
+      bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x143, 0xc, 0xf, false));
+      if (lane == 63 && bmax) atomicMax(&red[3], bmax);  // (one lane per wavefront: see the reductions after the tiles)
       __syncthreads();
       if (red[3] > 127) {  // workgroup-uniform: some prefix may leave int8 -- the lattice kernels decide exactly
         if (tid == 0) {
@@ -706,10 +712,24 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
         }
       }
     }
-    if (hx0) atomicAdd(reinterpret_cast<unsigned*>(&red[0]), hx0);
-    if (hx1) atomicAdd(reinterpret_cast<unsigned*>(&red[1]), hx1);
-    const int mabs = max(hi, -lo);
-    if (mabs) atomicMax(&red[2], mabs);
+    // Reduce inside the wavefront first (DPP), then ONE lane per wavefront touches the LDS word: 64 lanes doing an LDS
+    // atomic on the same address serialise -- the three atomics of all four wavefronts cost 5 200 cycles per game here
+    // (a quarter of the game's time; fine stamps, NOTES.md), found only after every other phase had been suspected.
+    {
+      const uint32_t s0 = wave_inclusive_scan(hx0), s1 = wave_inclusive_scan(hx1);  // lane 63: the wavefront's sums
+      int mabs = max(hi, -lo);
+      mabs = max(mabs, __builtin_amdgcn_update_dpp(0, mabs, 0x111, 0xf, 0xf, false));  // row_shr:1
+      mabs = max(mabs, __builtin_amdgcn_update_dpp(0, mabs, 0x112, 0xf, 0xf, false));  // row_shr:2
+      mabs = max(mabs, __builtin_amdgcn_update_dpp(0, mabs, 0x114, 0xf, 0xf, false));  // row_shr:4
+      mabs = max(mabs, __builtin_amdgcn_update_dpp(0, mabs, 0x118, 0xf, 0xf, false));  // row_shr:8
+      mabs = max(mabs, __builtin_amdgcn_update_dpp(0, mabs, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+      mabs = max(mabs, __builtin_amdgcn_update_dpp(0, mabs, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+      if (lane == 63) {
+        if (s0) atomicAdd(reinterpret_cast<unsigned*>(&red[0]), s0);
+        if (s1) atomicAdd(reinterpret_cast<unsigned*>(&red[1]), s1);
+        if (mabs) atomicMax(&red[2], mabs);
+      }
+    }
     TG_MSTAMP(stamp++);  // tiles (own part; elementwise pass included when wide)
     __syncthreads();  // image, action scalars and reductions complete
     TG_MSTAMP(stamp++);  // B2 passed
