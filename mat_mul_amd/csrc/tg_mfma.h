@@ -473,6 +473,25 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
     // ---- 1. factors (u negated: the products are subtracted), transposed into LDS; X0 into the image ----
     const __amdgpu_buffer_rsrc_t tok = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int8_t*>(a.actions + g * R * G::A3), 0, R * G::A3, 0x00027000);
+    // (the state is requested first: tokens and state then share ONE memory round trip)
+    constexpr int NCP = (G::NCHUNK + kBlock - 1) / kBlock;  // image chunks per thread
+    uint4 sq[NCP];
+    if (TG_MANY_ON(2)) {
+      const int8_t* src = a.in + g * a.in_stride;
+      if (G::TAIL != 0 && g == a.B - 1) {  // uniform: only the batch's last game may lack the bytes behind its tail
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) {  // (chunks past the end shadow the last one: no conditionally written registers)
+          const int c = tid + kBlock * i, cc = c < G::NCHUNK ? c : G::NCHUNK - 1;
+          sq[i] = load_chunk<G::TAIL>(src + 16 * cc, cc == G::NCHUNK - 1);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) {
+          const int c = tid + kBlock * i, cc = c < G::NCHUNK ? c : G::NCHUNK - 1;
+          sq[i] = *reinterpret_cast<const uint4*>(src + 16 * cc);
+        }
+      }
+    }
     int big = 0;
     if (srg < NRG && TG_MANY_ON(1)) {
       for (int rb = 4 * srg; rb < Rp; rb += 4 * NRG * TB) {
@@ -500,9 +519,11 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       }
     }
     if (TG_MANY_ON(2)) {
-      const int8_t* src = a.in + g * a.in_stride;
-      for (int c = tid; c < G::NCHUNK; c += kBlock)
-        *reinterpret_cast<uint4*>(img + 16 * c) = load_chunk<G::TAIL>(src + 16 * c, c == G::NCHUNK - 1);
+#pragma unroll
+      for (int i = 0; i < NCP; ++i) {
+        const int c = tid + kBlock * i;
+        if (c < G::NCHUNK) *reinterpret_cast<uint4*>(img + 16 * c) = sq[i];
+      }
     }
     if (tid < 4) red[tid] = 0;
     // workgroup OR of `big` with ONE barrier (HIP's __syncthreads_or costs three): red[4 + parity] was cleared during
