@@ -37,6 +37,9 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define A_MAD24(i) "v_mad_i32_i24 %" #i ", %8, %9, %" #i "\n\t"
 #define A_PKMAD(i) "v_pk_mad_i16 %" #i ", %8, %9, %" #i "\n\t"
 #define A_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n\t"
+#define A_MULHI(i) "v_mul_hi_u32 %" #i ", %" #i ", %8\n\t"
+#define A_MUL24(i) "v_mul_u32_u24 %" #i ", %" #i ", %8\n\t"
+
 #define A_DPP(i) "v_add_u32_dpp %" #i ", %8, %" #i " row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
 #define A_BFE(i) "v_bfe_i32 %" #i ", %" #i ", 8, 8\n\t"
 #define A_XOR(i) "v_xor_b32 %" #i ", %" #i ", %8\n\t"
@@ -50,10 +53,29 @@ K_VALU(k_align, A_ALIGN)
 K_VALU(k_mad24, A_MAD24)
 K_VALU(k_pkmad, A_PKMAD)
 K_VALU(k_mullo, A_MULLO)
+K_VALU(k_mulhi, A_MULHI)
+K_VALU(k_mul24, A_MUL24)
 K_VALU(k_dpp, A_DPP)
 K_VALU(k_bfe, A_BFE)
 K_VALU(k_xor, A_XOR)
 K_VALU(k_or3, A_OR3)
+
+__global__ void k_mad64(int n, unsigned* sink, unsigned long long* ticks) {
+  unsigned long long r[8];
+  unsigned y = blockIdx.x | 1, z = threadIdx.x;
+  for (int i = 0; i < 8; ++i) r[i] = threadIdx.x + i;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+  for (int i = 0; i < n; i += 32) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[j & 7]) : "v"(y), "v"(z) : "vcc");
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long x = 0;
+  for (int i = 0; i < 8; ++i) x ^= r[i];
+  if (x == 0xdeadbeefull) sink[0] = (unsigned)x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
+}
 
 __global__ void k_mfma(int n, unsigned* sink, unsigned long long* ticks) {
   v16i acc[2];
@@ -107,7 +129,7 @@ int main() {
   struct K { const char* name; void (*fn)(int, unsigned*, unsigned long long*); };
   K ks[] = {{"v_add_u32", k_add}, {"v_mov_b32", k_mov}, {"v_xor_b32", k_xor}, {"v_or3_b32", k_or3}, {"v_bfe_i32", k_bfe}, {"v_mul_i32_i24_sdwa (byte sel, preserve)", k_sdwa}, {"v_perm_b32", k_perm},
             {"v_max3_i32", k_max3}, {"v_alignbyte_b32", k_align}, {"v_mad_i32_i24", k_mad24}, {"v_pk_mad_i16", k_pkmad},
-            {"v_mul_lo_u32", k_mullo}, {"v_add_u32_dpp row_shr", k_dpp}, {"v_mfma_i32_32x32x32_i8", k_mfma},
+            {"v_mul_lo_u32", k_mullo}, {"v_mul_hi_u32", k_mulhi}, {"v_mul_u32_u24", k_mul24}, {"v_mad_u64_u32", k_mad64}, {"v_add_u32_dpp row_shr", k_dpp}, {"v_mfma_i32_32x32x32_i8", k_mfma},
             {"ds_read_b32", k_lds<1>},
             {"ds_read_u8", k_lds<2>}, {"ds_write_b32", k_lds<3>}, {"ds_write_b128", k_lds<4>}};
   printf("%-42s %28s %28s\n", "instruction", "1 wave/SIMD: cyc/instr", "4 waves/SIMD: cyc/instr per SIMD");
