@@ -47,7 +47,7 @@ struct GenArgs {
 #define TG_STAMP(i)                                                                                             \
   do {                                                                                                          \
     const int tg_stamp_i = (i);                                                                                 \
-    if (blockIdx.x < 20 && threadIdx.x == 0 && tg_stamp_i < 24)                                                 \
+    if (blockIdx.x < 20 && threadIdx.x == 0 && tg_stamp_i < 24 && ga.overflow)                                  \
       reinterpret_cast<unsigned long long*>(ga.overflow)[blockIdx.x * 24 + tg_stamp_i] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
