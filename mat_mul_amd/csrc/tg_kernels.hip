@@ -1470,9 +1470,10 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     // per-action scalars, verdict) outweighs the lattice kernels' K S^3 MACs only for long action lists; beyond
     // K = 127 the overflow bound cannot certify the reference's {-1,0,1} factors any more.
     const bool many_always = TG_SWITCH("TG_MFMA_MANY_ALWAYS");  // tests: every eligible shape
-    const bool pays = (a.S == 25 && a.nact >= 6) || (a.S == 16 && a.nact >= 40) || (a.S == 9 && a.nact >= 48);  // up to 256
-    // (tools/many_k_sweep.py: the matrix-core pass costs ~51 us at S=25 B=4096 whatever K is -- staging, tiles' fixed part,
-    //  verdict -- the lattice kernels 51.8 / 59.9 us at K = 4 / 8; S=16: 58-61 us against 24 / 42 / 57 / 65 at K = 8 / 20 / 32 / 40)
+    const bool pays = (a.S == 25 && a.nact >= 3) || (a.S == 16 && a.nact >= 20) || (a.S == 9 && a.nact >= 30);  // up to 256
+    // (tools/many_k_sweep.py, profiles/r02_many_k_sweep.txt: the matrix-core pass costs ~44.5 us at S=25 B=4096 and ~41 us at
+    //  S=16 B=8192 whatever K is -- staging, the tiles' fixed part, verdict; the lattice kernels 30 / 50 / 52 us at K = 2 / 3 / 4
+    //  (S=25), 24 / 35 / 41 / 45 / 55 at K = 8 / 16 / 20 / 24 / 32 (S=16), 58 / 82 / 106 against 88 / 96 / 99 at K = 12 / 24 / 32 (S=9))
     if (al && a.nact <= 256 && !force_i32 && !no_mfma && (a.S == 9 || a.S == 16 || a.S == 25) && (pays || many_always)) {
       const int Rp = (a.nact + 31) & ~31;
 #ifdef TG_AB_SWITCHES

@@ -249,7 +249,7 @@ def test_step_extreme_factors_full_int8_range(S):
             assert not want_ovf[0::4].any() and want_ovf.any()
 
 
-@pytest.mark.parametrize("S,K", [(25, 6), (25, 12), (25, 40), (25, 64), (25, 127), (16, 40), (16, 64), (16, 100), (9, 48), (9, 90)])
+@pytest.mark.parametrize("S,K", [(25, 6), (25, 12), (25, 40), (25, 64), (25, 127), (16, 20), (16, 40), (16, 64), (16, 100), (9, 30), (9, 48), (9, 90)])
 def test_step_many_matrix_core_path_verdicts(S, K):
     """tg_mfma.h many_mfma_kernel certifies a game only when its overflow bound holds and the zero state is
     reached at the last step or never; everything else goes to the lattice kernels through done_step.  One
@@ -391,7 +391,8 @@ def test_basis_tokens_matrix_core_path_large_entries(S, R):
     assert np.array_equal(host(ovf), ovf_o) and ovf_o[0] == 1 and ovf_o[1] == 0
 
 
-@pytest.mark.parametrize("S,B,K", [(4, 130, 7), (4, 5, 40), (9, 33, 12), (16, 9, 70), (25, 3, 130), (5, 6, 9), (2, 3, 3)])
+@pytest.mark.parametrize("S,B,K", [(4, 130, 7), (4, 5, 40), (9, 33, 12), (16, 9, 70), (25, 3, 130), (5, 6, 9), (2, 3, 3),
+                                   (25, 6, 3), (25, 5, 5), (25, 9, 2), (16, 11, 20), (16, 7, 19), (9, 13, 30), (9, 8, 29)])
 def test_step_many_matches_oracle(S, B, K):
     rng = np.random.default_rng(S * 31 + K)
     ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, K, 3 * S)).astype(np.int8)
