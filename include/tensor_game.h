@@ -79,8 +79,7 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
  * of training.py:266, free of charge); done[b] = (nnz[b] == 0).  With the count at hand a kernel need
  * not read the whole state: chunks that the action does not touch are neither loaded nor stored.
  * Same results as tg_step_i8.  Measured note: this moves far fewer bytes but is NOT faster than
- * tg_step_i8 on MI355X -- the step is bound by each wavefront's load->compute->store chain, not
- * by bandwidth -- so use it for the carried count, not for speed. */
+ * tg_step_i8 on MI355X, so use it for the carried count, not for speed. */
 int tg_step_sparse_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_t* done,
                       uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes, int shift,
                       tg_stream_t stream);

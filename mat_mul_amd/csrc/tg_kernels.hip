@@ -855,8 +855,7 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
 // (i = r + 4n, j), n = 0..3, i.e. chunks lane + 64 n.  The game's 48 tokens come straight into
 // registers (u and w as uniform dwordx4 loads, v_j as a byte), so there is no LDS staging and no
 // workgroup barrier: the wavefront's dependency chain is ONE memory round trip, arithmetic, stores.
-// (The staged packed_kernel needs three barriers; at S = 16 the step is bound by that chain per
-// wavefront, not by bandwidth -- see DESIGN.md.)  Factors beyond the 16-bit path's range are handled
+// (The staged packed_kernel needs three barriers.)  Factors beyond the 16-bit path's range are handled
 // by the same wavefront in 32-bit.  Requires 16-byte aligned state and actions.
 //
 // Arithmetic only where the action acts.  A row (i, j) changes only when u_i v_j != 0 -- 9 % of the rows under the
