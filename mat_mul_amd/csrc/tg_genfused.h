@@ -254,13 +254,14 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
           int8_t* const tcol = T + (x * S + 4 * h) * RS + r;
           uint8_t* const trow = tk + (3 * r + x) * S + 4 * h;
           const int lim = x < 2 ? G::UVLIM : 127, lim_lo = x < 2 ? -G::UVLIM : -128;
+          int fmx = 0, fmn = 0;  // range of the emitted factors: ONE test per job instead of five operations per value
           auto emit = [&](int t) {  // register t = row a0 + 4 h, a0 = (t & 3) + 8 (t >> 2)
             const int a0 = (t & 3) + 8 * (t >> 2);
-            const int f = acc[t], tokv = f + ga.shift;
-            big |= (f > lim) | (f < lim_lo);
-            bad |= tokv + 128;
+            const int f = acc[t];
+            fmx = max(fmx, f);
+            fmn = min(fmn, f);
             tcol[a0 * RS] = static_cast<int8_t>(f);
-            trow[a0] = static_cast<uint8_t>(tokv);
+            trow[a0] = static_cast<uint8_t>(f + ga.shift);
           };
 #pragma unroll
           for (int t = 0; t < 16; ++t)
@@ -270,6 +271,8 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
             for (int t = 0; t < 16; ++t)
               if ((t & 3) + 8 * (t >> 2) < S && (t & 3) + 8 * (t >> 2) + 4 >= S) emit(t);  // lower half only
           }
+          big |= (fmx > lim) | (fmn < lim_lo);
+          bad |= (fmx + ga.shift + 128) | (fmn + ga.shift + 128);  // a token outside int8 sets bits above the low byte
         }
       }
     }
