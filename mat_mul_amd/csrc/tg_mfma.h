@@ -469,7 +469,15 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
   (void)stamp;
   __syncthreads();
   TG_MSTAMP(1);  // set-up done
-  for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x) {
+  // A CU issues from its OLDEST workgroup first, so its four resident workgroups finish one after the other (11 us
+  // apart at S=25, K=64) and the last one runs alone at the end.  A workgroup that is ahead steps back (s_setprio):
+  // priority 3 while three or more games remain, 2 for the last but one, 1 for the first half of the last game, 0 for
+  // its tiles and verdict -- the laggards then overtake, and the four finish within ~4 us.
+  int games_left = static_cast<int>((a.B - 1 - static_cast<int64_t>(blockIdx.x)) / gridDim.x) + 1;
+  for (int64_t g = blockIdx.x; g < a.B; g += gridDim.x, --games_left) {
+    if (games_left >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (games_left == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
     // ---- 1. factors (u negated: the products are subtracted), transposed into LDS; X0 into the image ----
     const __amdgpu_buffer_rsrc_t tok = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int8_t*>(a.actions + g * R * G::A3), 0, R * G::A3, 0x00027000);
@@ -642,6 +650,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       }
     }
 
+    if (games_left == 1) __builtin_amdgcn_s_setprio(0);
     // ---- 2b. column tiles: acc = I X0 + W P ----
     int hi = 0, lo = 0;
     uint32_t hx0 = 0, hx1 = 0;
