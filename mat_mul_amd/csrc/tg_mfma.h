@@ -558,17 +558,25 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       const int* wu0 = uw == 2 ? g_fw.w[0] : g_fw.uv[0][uw];
       const int* wu1 = uw == 2 ? g_fw.w[1] : g_fw.uv[1][uw];
       for (int r = lane; r < Rp; r += 64) {
-        int d0 = 0, d1 = 0, mx = 0;
+        // (two accumulators per sum, running max and min instead of |b|: the dependent chains are half as long)
+        int d0a = 0, d0b = 0, d1a = 0, d1b = 0, bmx = 0, bmn = 0;
         const int8_t* colp = T + (uw * S) * RS + r;
 #pragma unroll
         for (int i = 0; i < S; ++i) {
           const int b = colp[i * RS];
-          d0 = mad24_sgpr(wu0[i], b, d0);
-          d1 = mad24_sgpr(wu1[i], b, d1);
-          mx = max(mx, max(b, -b));
+          if (i & 1) {
+            d0b = mad24_sgpr(wu0[i], b, d0b);
+            d1b = mad24_sgpr(wu1[i], b, d1b);
+          } else {
+            d0a = mad24_sgpr(wu0[i], b, d0a);
+            d1a = mad24_sgpr(wu1[i], b, d1a);
+          }
+          bmx = max(bmx, b);
+          bmn = min(bmn, b);
         }
-        sdot[(0 * 3 + wave) * Rp + r] = d0;
-        sdot[(1 * 3 + wave) * Rp + r] = d1;
+        const int mx = max(bmx, -bmn);
+        sdot[(0 * 3 + wave) * Rp + r] = d0a + d0b;
+        sdot[(1 * 3 + wave) * Rp + r] = d1a + d1b;
         smx[wave * Rp + r] = mx;
       }
     }
