@@ -147,9 +147,12 @@ __device__ __forceinline__ uint32_t draw_step16(uint32_t w, uint32_t c16, uint32
 }
 
 // eight draws (one Philox block) -> four dwords of two int16 values each: P[m] = values of elements 2m, 2m+1
+// TERNARY = true: the caller knows D.nthr == 2 (host-checked): the general form is not even compiled in, which keeps its
+// fourteen threshold / delta scalars out of the SGPR budget of the fused generator.
+template <bool TERNARY = false>
 __device__ __forceinline__ void draw_block16(const uint32_t (&w)[4], const Dist& D, uint32_t one, uint32_t base,
                                              uint32_t (&P)[4]) {
-  if (D.nthr == 2) {  // wave-uniform: the ternary vocabulary of the reference.  ONE asm statement: the four words are
+  if (TERNARY || D.nthr == 2) {  // wave-uniform: the ternary vocabulary of the reference.  ONE asm statement: the four words are
     // interleaved (independent chains) and no compiler padding separates the dependent packed ops
     uint32_t t0, t1, t2, t3;
     asm("v_pk_sub_u16 %4, %8, %12 clamp\n\tv_pk_sub_u16 %5, %9, %12 clamp\n\t"
@@ -167,6 +170,7 @@ __device__ __forceinline__ void draw_block16(const uint32_t (&w)[4], const Dist&
           "v"(one), "v"(base));
     return;
   }
+  if constexpr (TERNARY) return;
 #pragma unroll
   for (int m = 0; m < 4; ++m) P[m] = base;
 #pragma unroll

@@ -113,7 +113,8 @@ __device__ __forceinline__ int exact_target_from_tokens(const uint8_t* tok, int 
 // two wavefronts drawing twice while two wait, and 20 tiles as 4+4+3+3+3+3 instead of 5 each).
 // CHECK = false (host-proved, BASIS = false only): R * max|value|^3 <= 127, so no target entry can leave int8 and the
 // tiles skip their range tracking (the reference's {-1,0,1} with R <= 127).
-template <int S, int KS, bool BASIS, int NW, bool CHECK = true>
+// TERN: the distribution is the three-valued one (two thresholds), known on the host.
+template <int S, int KS, bool BASIS, int NW, bool CHECK = true, bool TERN = false>
 __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) {
   using G = MGeo<S>;
   constexpr int NTHREADS = 64 * NW;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
                                          k0, k1);
               const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
               uint32_t P[4];
-              draw_block16(ow, ga.D, one16, base16, P);
+              draw_block16<TERN>(ow, ga.D, one16, base16, P);
               Dw[2 * b] = __builtin_amdgcn_perm(P[1], P[0], 0x06040200u) & vmask[2 * b];
               Dw[2 * b + 1] = __builtin_amdgcn_perm(P[3], P[2], 0x06040200u) & vmask[2 * b + 1];
               if constexpr (!BASIS) {

@@ -1600,6 +1600,17 @@ int tg_internal_gen_fused(int8_t* target, int8_t* actions, uint8_t* overflow, co
   do {                                                                                             \
     const int ldsb = genfused_lds_bytes<S_>(Rp, R);                                                \
     static OccupancySlots occ;                                                                     \
+    if (D.nthr == 2 && KS_ != 0) {  /* the reference's three values: the specialised draw evaluation */ \
+      static OccupancySlots occ3;                                                                  \
+      const int per_cu3 = wgs_override > 0 ? wgs_override : resident_per_cu(gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true>, ldsb, occ3); \
+      const int64_t resident3 = static_cast<int64_t>(per_cu3) * device_cu_count() * (wgs_override > 0 ? 1 : 2); \
+      const int64_t per_wg3 = (B + resident3 - 1) / resident3;                                     \
+      const int64_t grid3 = (B + per_wg3 - 1) / per_wg3;                                           \
+      (void)hipGetLastError();                                                                     \
+      hipLaunchKernelGGL((gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true>), dim3((unsigned)grid3), dim3(kBlock), ldsb, st, ga, Rp); \
+      if (int rc = check_launch(fn)) return rc;                                                    \
+      return 1;                                                                                    \
+    }                                                                                              \
     const int per_cu = wgs_override > 0 ? wgs_override : resident_per_cu(gen_fused_kernel<S_, KS_, BAS_, 4, CHK_>, ldsb, occ); \
     /* twice as many workgroups as fit at once (two games each at B = 4096): the second wave of workgroups fills */ \
     /* the chip as the first ones finish, which evens out the tail (measured: 40 -> 38 us) */     \
