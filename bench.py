@@ -672,6 +672,23 @@ def also_lines(S_main, B_main, dev, mode):
                      "GBps": round(nbytes / sec / 1e9, 1), "hbm_frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
                      "TMACps": round(b2 * r2 * s2 ** 3 / sec / 1e12, 2),
                      "int8_mfma_frac": round(2 * b2 * r2 * s2 ** 3 / sec / 5.0e15, 4)})
+    # get_child_states with k > 1 (act.py:266-275, the shape MCTS expansion calls): k children per parent in one launch;
+    # bytes = parent read + k x (child written + tokens read + done + changed)
+    for s2, b2 in ((4, 65536), (4, 1 << 20), (16, 8192), (25, 4096)):
+        k2 = 8
+        tok, tgt = ops.gen_demos(b2, s2, k2, dev, seed=5)
+        kids = ops.alloc_states(b2 * k2, s2, dev).unflatten(0, (b2, k2))
+        kd = torch.zeros((b2, k2), dtype=torch.uint8, device=dev)
+        kc = torch.zeros((b2, k2), dtype=torch.uint8, device=dev)
+        sec = graph_time(lambda: ops.expand(tgt, tok, out=kids, done=kd, changed=kc), dev, reps=20 if b2 * s2 ** 3 < (32 << 20) else 5)
+        st, dn = ops.step(tgt, tok[:, k2 - 1].contiguous())      # self-check: child c == one step with action c
+        ok = bool(torch.equal(kids[:, k2 - 1], st)) and bool(torch.equal(kd[:, k2 - 1], dn))
+        nbytes = b2 * (s2 ** 3 + k2 * (s2 ** 3 + 3 * s2 + 2))
+        also.append({"workload": f"EXPAND tg_expand_i8: S={s2} batch={b2}, k={k2} children per parent in one launch "
+                                 f"(get_child_states with k > 1); a write stream: {k2 * b2 * s2 ** 3 / 1e6:.0f} MB of children",
+                     "ok": ok, "value": round(b2 * k2 / sec, 1), "unit": "children/s", "us_per_launch": round(sec * 1e6, 2),
+                     "GBps": round(nbytes / sec / 1e9, 1), "hbm_frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4)})
+        del kids, kd, kc, tok, tgt
     return also
 
 

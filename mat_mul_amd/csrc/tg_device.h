@@ -18,6 +18,19 @@ namespace tg {
 
 constexpr int kBlock = 256;  // 4 wavefronts of 64
 
+// Non-temporal 16-byte store, for the children of tg_expand_i8 at S = 4 (tools/expand_probe.hip, 2^20 parents x 8
+// children, 537 MB written: 146 us with plain stores, 97 us with nt stores; the product kernel 163 -> 110 us).
+// Measured and NOT adopted elsewhere: in-place streams gain nothing (78.2 / 78.1 us at 4 M games), the model-input
+// frames lose (f16, 2^20 games: 156 -> 175 us), S = 25 children lose (124 -> 136 us: 15 625-byte children end in
+// partial lines), S = 16 children are unchanged (56.5 / 57.1 us; NOTES.md: three forms of that kernel, same time).
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_nt(void* p, const uint4& q) {
+  __builtin_nontemporal_store(v4u_t{q.x, q.y, q.z, q.w}, reinterpret_cast<v4u_t*>(p));
+}
+// S = 4 children of at least this many bytes leave by non-temporal stores (half of the 256 MiB Infinity Cache: below
+// it the consumer may still find them there)
+constexpr int64_t kStreamOutBytes = 128ll << 20;
+
 // ---- packed int8 <-> int32 ------------------------------------------------------------------
 
 // sign-extended byte t (0..3) of a dword: one v_bfe_i32

@@ -62,6 +62,7 @@ struct ApplyArgs {
   int nact;
   int shift;
   int only_flagged;      // MANY: redo only the games whose done_step is kNeedsExact (second pass after tg_mfma.h)
+  int stream_out;        // EXPAND, S = 4: the children leave by non-temporal stores (output beyond kStreamOutBytes)
 };
 
 // done_step value by which many_mfma_kernel hands a game to the lattice kernels (never a valid result)
@@ -731,6 +732,7 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
 // team-per-parent loop in s4_kernel<EXPAND> writes 64-byte pieces 64 k bytes apart).  The k teams of
 // a parent read the same 16-byte parent slices: one request per wavefront, served from L1/L2.  A
 // workgroup takes PB = 64 / k whole parents (k <= 64); lc / k by multiplication (recip = ceil(2^16 / k)).
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void s4_expand_kernel(ApplyArgs a, int PB, int recip) {
   const int k = a.nact;
   const int lg = threadIdx.x >> 2, q = threadIdx.x & 3;
@@ -747,7 +749,11 @@ __global__ __launch_bounds__(kBlock) void s4_expand_kernel(ApplyArgs a, int PB, 
   uint32_t nz = 0;
   int ovf = 0;
   const uint4 o = s4_step_slice(par, du, dv, dw, q, a.shift, nz, ovf);
-  if (live) *reinterpret_cast<uint4*>(a.out + c0 * a.out_stride + (__umul24(lc, static_cast<uint32_t>(a.out_stride)) + 16u * q)) = o;
+  int8_t* const dst = a.out + c0 * a.out_stride + (__umul24(lc, static_cast<uint32_t>(a.out_stride)) + 16u * q);
+  if (live) {
+    if constexpr (NT) store16_nt(dst, o);
+    else *reinterpret_cast<uint4*>(dst) = o;
+  }
   const bool any_nz = team_any<4>(nz != 0);
   const bool any_ovf = team_any<4>((ovf & ~255) != 0);
   if (q == 0 && live) {
@@ -1217,6 +1223,19 @@ __global__ __launch_bounds__(kBlock) void broadcast_kernel(const int8_t* start, 
   if (vec16) {
     const int nchunk = (N + 15) >> 4, tail = N & 15;
     const int64_t total = (B - first) * nchunk;
+    if (total < (1ll << 31)) {  // the usual case: 32-bit index arithmetic (a 64-bit division is ~100 instructions)
+      const uint32_t tot = static_cast<uint32_t>(total), nc = static_cast<uint32_t>(nchunk);
+      for (uint32_t idx = static_cast<uint32_t>(tid); idx < tot; idx += static_cast<uint32_t>(nthr)) {
+        const uint32_t gi = idx / nc, c = idx - gi * nc;
+        int8_t* dst = out + (first + gi) * stride + 16 * c;
+        if (tail && c == nc - 1) {
+          for (int t = 0; t < tail; ++t) dst[t] = start[16 * c + t];
+        } else {
+          *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(start + 16 * c);
+        }
+      }
+      return;
+    }
     for (int64_t idx = tid; idx < total; idx += nthr) {
       const int64_t g = first + idx / nchunk;
       const int c = static_cast<int>(idx - (g - first) * nchunk);
@@ -1371,6 +1390,8 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
   const bool al = (MODE == GENF || (aligned16(a.in) && a.in_stride % 16 == 0)) && aligned16(a.out) &&
                   a.out_stride % 16 == 0;
   const int64_t B = a.B;
+  if constexpr (MODE == EXPAND)
+    a.stream_out = (B * a.nact * a.out_stride >= kStreamOutBytes || TG_SWITCH("TG_EXPAND_NT")) && !TG_SWITCH("TG_EXPAND_NO_NT");
 #ifdef TG_AB_SWITCHES
 #define TG_TEAM(S_, TS_)                                                                        \
   do {                                                                                          \
@@ -1389,7 +1410,9 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
         const int PB = 64 / a.nact, recip = (65536 + a.nact - 1) / a.nact;
         const int64_t eblocks = (B + PB - 1) / PB;
         if (eblocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
-        (void)hipGetLastError(); hipLaunchKernelGGL(s4_expand_kernel, dim3((unsigned)eblocks), dim3(kBlock), 0, st, a, PB, recip);
+        (void)hipGetLastError();
+        if (a.stream_out) hipLaunchKernelGGL(s4_expand_kernel<true>, dim3((unsigned)eblocks), dim3(kBlock), 0, st, a, PB, recip);
+        else hipLaunchKernelGGL(s4_expand_kernel<false>, dim3((unsigned)eblocks), dim3(kBlock), 0, st, a, PB, recip);
         return check_launch(fn);
       }
     }

@@ -1308,3 +1308,35 @@ def test_change_basis_matrix_core_kernel_and_its_fallbacks(S, B):
             assert np.array_equal(host(ovf), want_ovf), (S, sname, bname)
     want, want_ovf = O.change_basis_i8(tgt, Pm)
     assert (want_ovf == 0).sum() > 0                        # the sparse basis keeps some targets in range
+
+
+# ------------------------------------------------------------------ outputs beyond the cache
+@pytest.mark.parametrize("S,B,k", [(4, 262144, 8), (9, 23000, 8), (16, 4100, 8), (25, 1100, 8)])
+def test_streamed_outputs_match_the_cached_form(S, B, k):
+    """Outputs of >= 128 MiB (expand's children -- S = 4 writes them with non-temporal stores from that size on --,
+    copies, resets, model-input frames): the same bytes as a small slice of the batch gives, and (size-independent
+    property) child c of a parent == one step of the parent with action c."""
+    tok, tgt = ops.gen_demos(B, S, k, DEV, seed=S + 1)
+    tok[1, k - 1, :S] = 1                                      # a null action
+    kids, done, chg = ops.expand(tgt, tok)
+    assert kids.numel() >= 128 << 20 or S == 9                 # (S=9: 736-byte stride, 135 MB with padding)
+    n = 64
+    kids_small, done_small, chg_small = ops.expand(tgt[:n], tok[:n].contiguous())
+    assert torch.equal(kids[:n], kids_small) and torch.equal(done[:n], done_small) and torch.equal(chg[:n], chg_small)
+    for c in (0, k - 1):
+        st, dn = ops.step(tgt, tok[:, c].contiguous())
+        assert torch.equal(kids[:, c], st) and torch.equal(done[:, c], dn)
+    assert int(chg[1, k - 1]) == 0 and int(chg.sum()) < chg.numel()
+    # copies and resets of the children's buffer (same footprint)
+    flat = kids.flatten(0, 1)
+    cp = ops.copy_states(flat)
+    assert torch.equal(cp, flat)
+    ops.reset_broadcast(cp, tgt[0].contiguous())
+    assert bool((cp == tgt[0]).all())
+    del cp, kids
+    # model-input frames: float32 (B, T, S, S, S) of >= 128 MiB
+    T = max(2, -(-(128 << 20) // (B * S ** 3 * 4)))
+    ring = torch.randint(-3, 4, (B, T, S, S, S), dtype=torch.int8, device=DEV)
+    x, _ = ops.emit_frames(ring, T - 1, 0.0)
+    assert x.numel() * 4 >= 128 << 20
+    assert torch.equal(x, ring.flip(1).float())
