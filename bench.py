@@ -53,7 +53,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 INFINITY_CACHE_BYTES = 256 << 20
-STEP_KERNEL = {4: "tg::s4_kernel<0>", 9: "tg::s9_step_kernel", 25: "tg::s25_step_kernel"}
+STEP_KERNEL = {4: "tg::s4_kernel<0>", 9: "tg::s9_step_kernel<0>", 25: "tg::s25_step_kernel"}
 
 
 def step_kernel_name(S: int, B: int) -> str:
@@ -674,7 +674,7 @@ def also_lines(S_main, B_main, dev, mode):
                      "int8_mfma_frac": round(2 * b2 * r2 * s2 ** 3 / sec / 5.0e15, 4)})
     # get_child_states with k > 1 (act.py:266-275, the shape MCTS expansion calls): k children per parent in one launch;
     # bytes = parent read + k x (child written + tokens read + done + changed)
-    for s2, b2 in ((4, 65536), (4, 1 << 20), (16, 8192), (25, 4096)):
+    for s2, b2 in ((4, 65536), (4, 1 << 20), (9, 32768), (16, 8192), (25, 4096)):
         k2 = 8
         tok, tgt = ops.gen_demos(b2, s2, k2, dev, seed=5)
         kids = ops.alloc_states(b2 * k2, s2, dev).unflatten(0, (b2, k2))

@@ -1562,7 +1562,16 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
       const int64_t blocks = (B + 15) / 16;  // four wavefronts of four games
       if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
       (void)hipGetLastError();
-      hipLaunchKernelGGL(s9_step_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+      hipLaunchKernelGGL(s9_step_kernel<STEP>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+      return check_launch(fn);
+    }
+  }
+  if constexpr (MODE == EXPAND) {
+    // one 16-lane team per child (s9_step_kernel<EXPAND>): 80 -> 61 us at B = 32 768, k = 8
+    if (al && a.S == 9 && a.shift >= -127 && a.shift <= 127 && !force_i32 && !no_s9 && B * a.nact < 0x7fffffffLL) {
+      const int64_t blocks = (B * a.nact + 15) / 16;
+      (void)hipGetLastError();
+      hipLaunchKernelGGL(s9_step_kernel<EXPAND>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
       return check_launch(fn);
     }
   }

@@ -788,7 +788,14 @@ __global__ __launch_bounds__(kBlock, 7) void s25_step_kernel(ApplyArgs a) {  // 
 // saturating int16 multiply-adds (32-bit redo when the range test fails: exact or flagged, as everywhere), stores.
 // done / overflow per game: ballots -- the owners' over the unchanged chunks, the dense lanes' per team.
 // =============================================================================================
+//
+// MODE == EXPAND (tg_expand_i8): the same kernel with one team per CHILD g = parent * k + c -- "a step of the parent's
+// state with the child's action, written to slot g", as s4_expand_kernel -- plus the `changed` byte.  All 16 lanes busy
+// and arithmetic only on the candidate chunks, where packed_kernel<9,16,EXPAND> keeps 9 of 16 lanes busy and does the
+// whole unpack / multiply-add / pack for every chunk of every child (B = 32 768, k = 8: 80 us; this form 61 us).
+template <int MODE>
 __global__ __launch_bounds__(kBlock, 6) void s9_step_kernel(ApplyArgs a) {  // (14 spills at 64 VGPRs)
+  static_assert(MODE == STEP || MODE == EXPAND, "s9_step_kernel: single step or expand");
   constexpr int S = 9, TS = 16;
   using G = PGeo<S, TS>;  // (UVLEN, WE, FSTRIDE, NCHUNK, TAIL as in packed_kernel<9, 16>)
   static_assert(G::FSTRIDE <= 5 * TS && G::NCHUNK <= 3 * TS && G::TAIL == 9, "s9_step_kernel geometry");
@@ -800,10 +807,12 @@ __global__ __launch_bounds__(kBlock, 6) void s9_step_kernel(ApplyArgs a) {  // (
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int team = lane >> 4, lt = lane & 15;
   int64_t g = (static_cast<int64_t>(blockIdx.x) * NWAVE + wave) * GPW + team;
-  const bool live = g < a.B;
-  if (!live) g = a.B - 1;
+  const int64_t ngames = MODE == EXPAND ? a.B * a.nact : a.B;  // (EXPAND: below 2^31, checked on the host)
+  const bool live = g < ngames;
+  if (!live) g = ngames - 1;
   const int8_t* const tok = a.actions + g * (3 * S);
-  const int8_t* const in = a.in + g * a.in_stride;
+  const int64_t gin = MODE == EXPAND ? static_cast<int64_t>(static_cast<uint32_t>(g) / static_cast<uint32_t>(a.nact)) : g;
+  const int8_t* const in = a.in + gin * a.in_stride;
   int8_t* const out = a.out + g * a.out_stride;
   short* const Fg = F[wave * GPW + team];
   // ---- loads: the lane's table entries (tokens) first, then its three chunks ----
@@ -827,7 +836,7 @@ __global__ __launch_bounds__(kBlock, 6) void s9_step_kernel(ApplyArgs a) {  // (
   }
   // whole 16-byte chunks; the last chunk's bytes past S^3 = 729 lie inside the game's stride (736) except, possibly,
   // for the LAST game of the batch, which takes load_chunk's byte-wise tail
-  const bool last_game = g == a.B - 1;
+  const bool last_game = gin == a.B - 1;
   auto load = [&](int c) {
     uint4 q = uint4{0, 0, 0, 0};
     if (c < G::NCHUNK) q = (c == G::NCHUNK - 1 && last_game) ? load_chunk<G::TAIL>(in + 16 * c, true) : *reinterpret_cast<const uint4*>(in + 16 * c);
@@ -852,7 +861,7 @@ __global__ __launch_bounds__(kBlock, 6) void s9_step_kernel(ApplyArgs a) {  // (
     }
   }
   __syncthreads();  // (only for `below`, written once per workgroup; the tables are wavefront-local)
-  const bool inplace = a.in == a.out;
+  const bool inplace = MODE == STEP && a.in == a.out;
   uint32_t nz = 0, ovf = 0;
   auto differs = [](const uint4& x, const uint4& y) { return x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w; };
 
@@ -970,7 +979,7 @@ __global__ __launch_bounds__(kBlock, 6) void s9_step_kernel(ApplyArgs a) {  // (
       dnz = 0;
       const uint32_t ovf_before = ovf;
       ovf = 0;
-      finish(x, me.x & 255, F[wave * GPW + dteam], a.out + (gd < a.B ? gd : a.B - 1) * a.out_stride, gd < a.B, me.y, me.z, me.w);
+      finish(x, me.x & 255, F[wave * GPW + dteam], a.out + (gd < ngames ? gd : ngames - 1) * a.out_stride, gd < ngames, me.y, me.z, me.w);
       if (dnz) dnz_t |= 1u << dteam;
       if (ovf) ovf_t |= 1u << dteam;
       ovf = ovf_before;
@@ -986,6 +995,16 @@ __global__ __launch_bounds__(kBlock, 6) void s9_step_kernel(ApplyArgs a) {  // (
     if (t == team) {
       any_nz = any_nz || tnz;
       any_ovf = tov;
+    }
+  }
+  if constexpr (MODE == EXPAND) {
+    if (a.changed) {  // null action <=> u, v or w is the zero vector (the team's table: -u | 0 | v | pad | w ...)
+      const bool mine = lt < S;
+      const unsigned long long bu = __ballot(mine && Fg[lt] != 0), bv = __ballot(mine && Fg[S + 1 + lt] != 0),
+                               bw = __ballot(mine && Fg[G::UVLEN + lt] != 0);
+      const int sh = 16 * team;
+      const bool nonnull = ((bu >> sh) & 0xFFFFull) != 0 && ((bv >> sh) & 0xFFFFull) != 0 && ((bw >> sh) & 0xFFFFull) != 0;
+      if (lt == 0 && live) a.changed[g] = nonnull ? 1 : 0;
     }
   }
   if (lt == 0 && live) {
