@@ -175,13 +175,23 @@ __global__ __launch_bounds__(kBlock) void hash_kernel(const int8_t* state, uint6
     int body_words = 0;
     if (vec16) {
       body_words = (N >> 4) << 1;  // whole 16-byte chunks
-      for (int c = lt; 16 * c + 16 <= N; c += lpg) {
-        const uint4 q = *reinterpret_cast<const uint4*>(p + 16 * c);
+      auto mix = [&](const uint4& q, int c) {
         const uint64_t w0 = static_cast<uint64_t>(q.x) | (static_cast<uint64_t>(q.y) << 32);
         const uint64_t w1 = static_cast<uint64_t>(q.z) | (static_cast<uint64_t>(q.w) << 32);
         h += fmix64(w0 + static_cast<uint64_t>(2 * c + 1) * 0x9E3779B97F4A7C15ull);
         h += fmix64(w1 + static_cast<uint64_t>(2 * c + 2) * 0x9E3779B97F4A7C15ull);
+      };
+      const int nc = N >> 4;  // whole chunks
+      int c = lt;
+      for (; c + 3 * lpg < nc; c += 4 * lpg) {  // four chunks in flight per lane
+        const uint4 q0 = *reinterpret_cast<const uint4*>(p + 16 * c), q1 = *reinterpret_cast<const uint4*>(p + 16 * (c + lpg)),
+                    q2 = *reinterpret_cast<const uint4*>(p + 16 * (c + 2 * lpg)), q3 = *reinterpret_cast<const uint4*>(p + 16 * (c + 3 * lpg));
+        mix(q0, c);
+        mix(q1, c + lpg);
+        mix(q2, c + 2 * lpg);
+        mix(q3, c + 3 * lpg);
       }
+      for (; c < nc; c += lpg) mix(*reinterpret_cast<const uint4*>(p + 16 * c), c);
     }
     for (int k = body_words + lt; k < nword; k += lpg) {  // remaining words, byte by byte, zero padded
       uint64_t w = 0;

@@ -69,10 +69,10 @@ __device__ __forceinline__ int mad24_sgpr(int a_uniform, int b, int c) {
 
 // number of non-zero bytes of a dword: fold each byte onto its low bit, then popcount
 __device__ __forceinline__ int count_nonzero_bytes(uint32_t x) {
-  x |= x >> 4;
-  x |= x >> 2;
-  x |= x >> 1;
-  return __popc(x & 0x01010101u);
+  // bit 7 of a byte <- "byte != 0": adding 0x7f to the low seven bits carries into bit 7 iff they are non-zero, OR x
+  // brings in bit 7 itself (no carry leaves a byte: 0x7f + 0x7f < 0x100); five instructions, the popcount accumulates
+  const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
+  return __popc(t & 0x80808080u);
 }
 __device__ __forceinline__ int count_nonzero_bytes(const uint4& q) {
   return count_nonzero_bytes(q.x) + count_nonzero_bytes(q.y) + count_nonzero_bytes(q.z) + count_nonzero_bytes(q.w);

@@ -1200,10 +1200,14 @@ __global__ __launch_bounds__(kBlock) void done_kernel(const int8_t* state, uint8
     int cnt = 0, body = 0;
     if (vec16) {
       body = N & ~15;
-      for (int e = 16 * lt; e < body; e += 16 * lpg) {
-        const uint4 q = *reinterpret_cast<const uint4*>(p + e);
-        cnt += count_nonzero_bytes(q);
+      const int step = 16 * lpg;
+      int e = 16 * lt;
+      for (; e + 3 * step < body; e += 4 * step) {  // four chunks in flight per lane (S=16: the game in one round trip)
+        const uint4 q0 = *reinterpret_cast<const uint4*>(p + e), q1 = *reinterpret_cast<const uint4*>(p + e + step),
+                    q2 = *reinterpret_cast<const uint4*>(p + e + 2 * step), q3 = *reinterpret_cast<const uint4*>(p + e + 3 * step);
+        cnt += count_nonzero_bytes(q0) + count_nonzero_bytes(q1) + count_nonzero_bytes(q2) + count_nonzero_bytes(q3);
       }
+      for (; e < body; e += step) cnt += count_nonzero_bytes(*reinterpret_cast<const uint4*>(p + e));
     }
     for (int e = body + lt; e < N; e += lpg) cnt += p[e] != 0;
     for (int off = lpg >> 1; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);

@@ -44,4 +44,10 @@ for t in read_bw_probe issue_rate_probe shader_clock_probe; do
   $OUT/$t > $OUT/$t.txt 2> $OUT/$t.err || exit 1
   rm -f $OUT/$t
 done
+# 8. write-stream patterns behind tg_expand_i8 (plain against non-temporal stores), and the byte-streaming entries either
+#    side of the step by graph replay
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-result $R/tools/expand_probe.hip -o $OUT/expand_probe > $OUT/expand_probe_build.log 2>&1 || exit 1
+( echo "---- 1048576 parents x 8 children ----"; $OUT/expand_probe 1048576; echo "---- 65536 parents x 8 children ----"; $OUT/expand_probe 65536 ) > $OUT/expand_probe.txt 2> $OUT/expand_probe.err || exit 1
+rm -f $OUT/expand_probe
+python3 $R/tools/aux_time.py > $OUT/aux_ops.txt 2> $OUT/aux_ops.err || exit 1
 echo profiles done

@@ -62,7 +62,8 @@ for name in ("bench_driver", "bench_graph", "bench_graph_S16", "bench_eager", "b
 lf = src / "launch_floor.txt"
 if lf.exists():
     shutil.copy(lf, dst / f"{tag}_launch_floor.txt")
-for probe, name in (("read_bw_probe", "read_bandwidth"), ("issue_rate_probe", "issue_rates"), ("shader_clock_probe", "shader_clock")):
+for probe, name in (("read_bw_probe", "read_bandwidth"), ("issue_rate_probe", "issue_rates"), ("shader_clock_probe", "shader_clock"),
+                    ("expand_probe", "expand_probe"), ("aux_ops", "aux_ops")):
     if (src / f"{probe}.txt").exists():
         shutil.copy(src / f"{probe}.txt", dst / f"{tag}_{name}.txt")
 

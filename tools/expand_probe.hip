@@ -1,4 +1,7 @@
-// memory-pattern probe for tg_expand_i8 at S=4: B parents, k=8 children each
+// Memory-pattern probe for tg_expand_i8 at S=4 (B parents, k=8 children each, no arithmetic): what the write stream
+// costs with plain and with non-temporal stores, with and without the token / done / changed traffic.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-result tools/expand_probe.hip -o /tmp/ep && /tmp/ep 1048576
+// Output of one run: profiles/r02_expand_probe.txt.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -57,10 +60,12 @@ int main(int argc, char** argv) {
   const unsigned grid = (unsigned)((nchild * 4 + 255) / 256);
   auto run = [&](const char* name, auto launch, double bytes) {
     for (int i = 0; i < 3; ++i) launch();
-    hipEventRecord(e0, s);
+    (void)hipEventRecord(e0, s);
     for (int i = 0; i < 10; ++i) launch();
-    hipEventRecord(e1, s); hipStreamSynchronize(s);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventRecord(e1, s);
+    (void)hipStreamSynchronize(s);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
     printf("%-44s %8.1f us  %6.0f GB/s\n", name, ms * 100, bytes / (ms * 1e-4) / 1e9);
     return 0;
   };
