@@ -2,7 +2,8 @@
 """Randomised differential soak of the single-step kernels (S=16 / S=25 compaction queues and their dense-factor
 paths, the whole-line variant, S=4, the staged kernels) and of the streamed stepper against the numpy oracle:
 token densities swept so that the candidate count crosses the queue capacity (64), wide factors, large shifts,
-states at the int8 edge, null actions, in place / out of place, padded / packed layouts.
+states at the int8 edge, null actions, in place / out of place, padded / packed layouts; and of tg_expand_i8 on
+the same material (children, done, changed, overflow).
     python tools/stress_step.py [cases]          (TG_LIB_VARIANT=ab TG_S16_LINES=1 ... for the forced variants)"""
 import sys
 from pathlib import Path
@@ -71,6 +72,17 @@ for c in range(cases):
         torch.cuda.synchronize()
         ok = ok and np.array_equal(t.cpu().numpy(), cur) and np.array_equal(done.cpu().numpy(), wd)
         ok = ok and np.array_equal(ovf.cpu().numpy(), wo)
+    # tg_expand_i8 on the same material: k children per parent (the game's own action and its neighbours')
+    k = int(rng.integers(1, 9))
+    ak = np.stack([np.roll(tok, j, axis=0) for j in range(k)], axis=1)
+    wk, wd, wc, wo = O.expand_i8(st, ak, shift)
+    for layout in ("padded", "packed"):
+        t = padded(st) if layout == "padded" else torch.from_numpy(st).to(DEV)
+        ovk = torch.zeros((B, k), dtype=torch.uint8, device=DEV)
+        kids, d, ch = ops.expand(t, torch.from_numpy(ak).to(DEV), overflow=ovk, shift=shift)
+        ok = ok and np.array_equal(kids.cpu().numpy(), wk) and np.array_equal(d.cpu().numpy(), wd)
+        ok = ok and np.array_equal(ch.cpu().numpy(), wc) and np.array_equal(ovk.cpu().numpy(), wo)
+        ok = ok and np.array_equal(t.cpu().numpy(), st)
     if not ok:
         bad += 1
         print("MISMATCH", dict(case=c, S=S, B=B, shift=shift, dens=dens, kind=kind), flush=True)
