@@ -58,8 +58,10 @@ STEP_KERNEL = {4: "tg::s4_kernel<0>", 9: "tg::s9_step_kernel<0>", 25: "tg::s25_s
 
 def step_kernel_name(S: int, B: int) -> str:
     """The kernel tg_step_i8 launches for aligned int8 states (tg_kernels.hip, apply_launch)."""
-    if S == 16:  # whole-line stores from 96 MiB of states on
-        return "tg::s16_step_kernel<0, true>" if B * 4096 >= (96 << 20) else "tg::s16_step_kernel<0, false>"
+    if S == 16:  # whole-line stores from 96 MiB of states on, non-temporal state loads from 384 MiB on
+        if B * 4096 >= (384 << 20):
+            return "tg::s16_step_kernel<0, true, true>"
+        return "tg::s16_step_kernel<0, true, false>" if B * 4096 >= (96 << 20) else "tg::s16_step_kernel<0, false, false>"
     return STEP_KERNEL.get(S, "tg::slow_kernel<0>")
 
 

@@ -921,7 +921,11 @@ __device__ __forceinline__ uint4 s16_chunk(const uint4& x, int uvn, const uint32
 // 131 072 games: 148 us with 16-byte or 64-byte stores, 130 us with whole lines, although those write 1.7x the bytes).
 // The dense pass then hands its results back through the queue and the owners store.  Cache-resident batches keep the
 // 16-byte stores straight from the dense pass (no second trip through LDS: 5.8 us against 6.2 at BASELINE config 3).
-template <int MODE, bool LINES>
+// NTL: the state is read by non-temporal loads.  With whole-line stores and a batch beyond the 256 MiB Infinity Cache
+// that is worth a quarter of the launch (131 072 games = 512 MiB: 131.5 -> 99.0 us; 262 144 games: 260 -> 232); up to
+// 256 MiB it is neutral to harmful (65 536 games: 50.3 / 52.0 us, BASELINE config 3: 6.0 / 8.5), and the S = 25 step,
+// whose stores are 16-byte pieces, gains nothing at any size (143.1 / 143.0 us at 32 768 games).
+template <int MODE, bool LINES, bool NTL = false>
 __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyArgs a) {  // (LINES keeps the inputs to the end)
   static_assert(MODE == STEP, "s16_step_kernel: single step only");
   constexpr int QCAP = 64;  // queue entries per wavefront
@@ -936,8 +940,15 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
   const int8_t* src = a.in + g * a.in_stride + 16 * lane;
   // every load of the wavefront is issued before anything is used.  (Four named chunks, not an array: hipcc keeps an
   // array that lives to the end of the LINES variant in scratch.)
-  const uint4 p0 = *reinterpret_cast<const uint4*>(src), p1 = *reinterpret_cast<const uint4*>(src + 1024),
-              p2 = *reinterpret_cast<const uint4*>(src + 2048), p3 = *reinterpret_cast<const uint4*>(src + 3072);
+  auto ld = [&](const int8_t* q) {
+    if constexpr (NTL) {
+      const v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(q));
+      return uint4{v.x, v.y, v.z, v.w};
+    } else {
+      return *reinterpret_cast<const uint4*>(q);
+    }
+  };
+  const uint4 p0 = ld(src), p1 = ld(src + 1024), p2 = ld(src + 2048), p3 = ld(src + 3072);
   const uint4 uq = *reinterpret_cast<const uint4*>(tok);
   const uint4 wq = *reinterpret_cast<const uint4*>(tok + 32);
   auto wfetch = [&]() { return *reinterpret_cast<const uint4*>(tok + 32); };
@@ -1552,7 +1563,9 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
       (void)hipGetLastError();
       // whole-line stores pay from ~100 MiB of states on (measured: 6.0 / 7.0 us at 32 MiB, 26.3 / 25.5 at 128 MiB,
       // 50.3 / 47.0 at 256 MiB, 150 / 128 at 512 MiB, 16-byte stores / whole lines)
-      if (B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES"))  // (A/B switch: tests at small batches)
+      if (B * a.in_stride >= (384ll << 20) || TG_SWITCH("TG_S16_NT_LOADS"))  // beyond the Infinity Cache (A/B switch: tests)
+        hipLaunchKernelGGL((s16_step_kernel<MODE, true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+      else if (B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES"))  // (A/B switch: tests at small batches)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
       else
         hipLaunchKernelGGL((s16_step_kernel<MODE, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
