@@ -53,15 +53,19 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 INFINITY_CACHE_BYTES = 256 << 20
-STEP_KERNEL = {4: "tg::s4_kernel<0>", 9: "tg::s9_step_kernel<0>", 25: "tg::s25_step_kernel"}
+STEP_KERNEL = {4: "tg::s4_kernel<0>", 9: "tg::s9_step_kernel<0>"}
 
 
 def step_kernel_name(S: int, B: int) -> str:
     """The kernel tg_step_i8 launches for aligned int8 states (tg_kernels.hip, apply_launch)."""
-    if S == 16:  # whole-line stores from 96 MiB of states on, non-temporal state loads from 384 MiB on
-        if B * 4096 >= (384 << 20):
+    if S == 16:  # whole-line stores from 96 MiB of states on, non-temporal state loads from 320 MiB on
+        if B * 4096 >= (320 << 20):
             return "tg::s16_step_kernel<0, true, true>"
         return "tg::s16_step_kernel<0, true, false>" if B * 4096 >= (96 << 20) else "tg::s16_step_kernel<0, false, false>"
+    if S == 25:  # the same two thresholds on 15 632-byte game strides
+        if B * 15632 >= (320 << 20):
+            return "tg::s25_step_kernel<true, true>"
+        return "tg::s25_step_kernel<true, false>" if B * 15632 >= (96 << 20) else "tg::s25_step_kernel<false, false>"
     return STEP_KERNEL.get(S, "tg::slow_kernel<0>")
 
 
@@ -578,7 +582,8 @@ def also_lines(S_main, B_main, dev, mode):
             (4, 1 << 20, 112, "BASELINE config 4 on ONE GPU (67 MB of states)", "demo"),
             (4, 1 << 22, 112, "HBM-streaming batch (268 MB of states)", "demo"),
             (25, 4096, 208, "config 5 per-GPU step", "demo"),
-            (16, 1 << 17, 64, "HBM-streaming batch (537 MB of states)", "demo")]:
+            (16, 1 << 17, 64, "HBM-streaming batch (537 MB of states)", "demo"),
+            (25, 1 << 15, 64, "BASELINE config 5 whole on ONE GPU (512 MB of states, streams from HBM)", "demo")]:
         if kind == "demo" and s2 == S_main and b2 == B_main:
             continue
         if kind == "demo":

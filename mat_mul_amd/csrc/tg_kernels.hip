@@ -923,8 +923,9 @@ __device__ __forceinline__ uint4 s16_chunk(const uint4& x, int uvn, const uint32
 // 16-byte stores straight from the dense pass (no second trip through LDS: 5.8 us against 6.2 at BASELINE config 3).
 // NTL: the state is read by non-temporal loads.  With whole-line stores and a batch beyond the 256 MiB Infinity Cache
 // that is worth a quarter of the launch (131 072 games = 512 MiB: 131.5 -> 99.0 us; 262 144 games: 260 -> 232); up to
-// 256 MiB it is neutral to harmful (65 536 games: 50.3 / 52.0 us, BASELINE config 3: 6.0 / 8.5), and the S = 25 step,
-// whose stores are 16-byte pieces, gains nothing at any size (143.1 / 143.0 us at 32 768 games).
+// ~300 MiB it is neutral to harmful (77 000 games = 301 MiB: 58.7 / 60.3 us, 65 536 games: 50.3 / 52.0, BASELINE config
+// 3: 6.0 / 8.5), from 86 000 games = 336 MiB on it wins (80.0 / 66.4): taken from 320 MiB on.  Without whole-line stores
+// (the S = 25 step as it was: 16-byte pieces) it gains nothing at any size (143.1 / 143.0 us at 32 768 games).
 template <int MODE, bool LINES, bool NTL = false>
 __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyArgs a) {  // (LINES keeps the inputs to the end)
   static_assert(MODE == STEP, "s16_step_kernel: single step only");
@@ -1563,7 +1564,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
       (void)hipGetLastError();
       // whole-line stores pay from ~100 MiB of states on (measured: 6.0 / 7.0 us at 32 MiB, 26.3 / 25.5 at 128 MiB,
       // 50.3 / 47.0 at 256 MiB, 150 / 128 at 512 MiB, 16-byte stores / whole lines)
-      if (B * a.in_stride >= (384ll << 20) || TG_SWITCH("TG_S16_NT_LOADS"))  // beyond the Infinity Cache (A/B switch: tests)
+      if (B * a.in_stride >= (320ll << 20) || TG_SWITCH("TG_S16_NT_LOADS"))  // beyond the Infinity Cache (A/B switch: tests)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
       else if (B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES"))  // (A/B switch: tests at small batches)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
@@ -1596,7 +1597,14 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     // (|shift| <= 127: factors within +-255, which the 32-bit redo of s25_step_kernel takes from its int16 tables)
     if (al && a.S == 25 && a.shift >= -127 && a.shift <= 127 && B <= 0x7fffffffLL && !force_i32 && !no_s25) {
       (void)hipGetLastError();
-      hipLaunchKernelGGL(s25_step_kernel, dim3((unsigned)B), dim3(kBlock), 0, st, a);
+      // as at S=16: whole-line stores once the batch leaves the caches, non-temporal state loads beyond the Infinity
+      // Cache (A/B switches: the variants at test sizes)
+      if (B * a.in_stride >= (320ll << 20) || TG_SWITCH("TG_S25_NT_LOADS"))
+        hipLaunchKernelGGL((s25_step_kernel<true, true>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
+      else if (B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S25_LINES"))
+        hipLaunchKernelGGL((s25_step_kernel<true, false>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
+      else
+        hipLaunchKernelGGL((s25_step_kernel<false, false>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
       return check_launch(fn);
     }
   }

@@ -615,7 +615,14 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
 // lane k takes entry k: window from the table at the chunk's own position, arithmetic, store.  Unchanged chunks only
 // feed the zero test.  A wavefront with more than 64 candidates does its chunks directly.
 // =============================================================================================
-__global__ __launch_bounds__(kBlock, 7) void s25_step_kernel(ApplyArgs a) {  // (6 spills at 64 VGPRs)
+//
+// LINES / NTL (batches that stream from HBM, as s16_step_kernel's): the dense pass hands its results back through the
+// queue and every lane stores its own chunks at 128-byte-LINE granularity -- a chunk is stored when any chunk of its
+// line changed (a game starts 16 g bytes into a line, so the eight chunks of a line are eight consecutive lanes from
+// lane (-(g + 250 n)) mod 8 on; lines that straddle two wavefronts or two games stay partial) -- and, beyond the
+// Infinity Cache, the state is read by non-temporal loads.
+template <bool LINES, bool NTL>
+__global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyArgs a) {  // (6 spills at 64 VGPRs)
   constexpr int S = 25;
   using G = PGeo<S, kBlock>;
   static_assert(G::NSEG == 2 && G::NCH == 4 && G::FSTRIDE <= kBlock, "s25_step_kernel geometry");
@@ -649,7 +656,14 @@ __global__ __launch_bounds__(kBlock, 7) void s25_step_kernel(ApplyArgs a) {  // 
   auto load = [&](int n) {
     const int c = lt + G::TSA * n;
     uint4 q = uint4{0, 0, 0, 0};
-    if (active && c < G::NCHUNK) q = load_chunk<G::TAIL>(in + 16 * c, G::TAIL != 0 && c == G::NCHUNK - 1);
+    if (active && c < G::NCHUNK) {
+      if (NTL && !(G::TAIL != 0 && c == G::NCHUNK - 1)) {
+        const v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(in + 16 * c));
+        q = uint4{v.x, v.y, v.z, v.w};
+      } else {
+        q = load_chunk<G::TAIL>(in + 16 * c, G::TAIL != 0 && c == G::NCHUNK - 1);
+      }
+    }
     return q;
   };
   const uint4 p0 = load(0), p1 = load(1), p2 = load(2), p3 = load(3);
@@ -709,7 +723,7 @@ __global__ __launch_bounds__(kBlock, 7) void s25_step_kernel(ApplyArgs a) {  // 
 
   // ---- which of the lane's chunks does the action touch?  candidates -> the wavefront's queue ----
   int total = 0;  // wave-uniform
-  auto enqueue = [&](int n, const uint4& pn, int& uv0, int& uv1) {
+  auto enqueue = [&](int n, const uint4& pn, int& uv0, int& uv1, int& slot) {
     const int c = lt + G::TSA * n;
     const bool cv = active && c < G::NCHUNK;
     const int r0 = (16 * c) / S, l0 = (16 * c) % S;  // row (i, j) of the chunk's first element; the second row is r0 + 1
@@ -727,8 +741,8 @@ __global__ __launch_bounds__(kBlock, 7) void s25_step_kernel(ApplyArgs a) {  // 
     uv1 = uv[1];
     const bool cand = (uv0 | uv1) != 0;
     const unsigned long long m = __ballot(cand);
-    const int slot = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
+    slot = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
     if (cand) {
       if (slot < QCAP) {
         qd[wave][slot] = pn;
@@ -736,15 +750,15 @@ __global__ __launch_bounds__(kBlock, 7) void s25_step_kernel(ApplyArgs a) {  // 
       }
     } else {
       nz |= pn.x | pn.y | pn.z | pn.w;
-      if (!inplace && cv) store_chunk<G::TAIL>(out + 16 * c, pn, G::TAIL != 0 && c == G::NCHUNK - 1);
+      if (!LINES && !inplace && cv) store_chunk<G::TAIL>(out + 16 * c, pn, G::TAIL != 0 && c == G::NCHUNK - 1);
     }
     total += __builtin_popcountll(m);
   };
-  int u00, u01, u10, u11, u20, u21, u30, u31;
-  enqueue(0, p0, u00, u01);
-  enqueue(1, p1, u10, u11);
-  enqueue(2, p2, u20, u21);
-  enqueue(3, p3, u30, u31);
+  int u00, u01, u10, u11, u20, u21, u30, u31, s0, s1, s2, s3;
+  enqueue(0, p0, u00, u01, s0);
+  enqueue(1, p1, u10, u11, s1);
+  enqueue(2, p2, u20, u21, s2);
+  enqueue(3, p3, u30, u31, s3);
   auto finish = [&](const uint4& x, int c, int uv0, int uv1) {
     uint32_t cnz;
     const uint4 res = chunk(x, c, uv0, uv1, cnz);
@@ -758,14 +772,49 @@ __global__ __launch_bounds__(kBlock, 7) void s25_step_kernel(ApplyArgs a) {  // 
     if (lane < total) {
       const uint4 x = qd[wave][lane];
       const int4 me = qm[wave][lane];
-      finish(x, me.x, me.y, me.z);
+      if constexpr (LINES) {
+        uint32_t cnz;
+        qd[wave][lane] = chunk(x, me.x, me.y, me.z, cnz);  // back to the owner, who stores whole lines
+        nz |= cnz;
+      } else {
+        finish(x, me.x, me.y, me.z);
+      }
+    }
+    if constexpr (LINES) {
+      __builtin_amdgcn_wave_barrier();
+      auto own = [&](int n, const uint4& pn, bool cand, int slot) {
+        const int c = lt + G::TSA * n;
+        const bool cv = active && c < G::NCHUNK;
+        uint4 res = pn;
+        if (cand) res = qd[wave][slot];
+        const bool chg = cv && differs(res, pn);
+        bool st = cv;  // out of place everything is written
+        if (inplace) {
+          // the lanes of my line: (g + c) >> 3 equal, i.e. eight consecutive lanes from a multiple of 8 minus sh on
+          const unsigned long long m = __ballot(chg);
+          const int sh = static_cast<int>((g + G::TSA * n) & 7);
+          const int first = ((lane + sh) & ~7) - sh;  // may be negative: the line began in the previous wavefront
+          const int lo = max(first, 0), hi = min(first + 8, 64);
+          st = ((m >> lo) & ((1ull << (hi - lo)) - 1ull)) != 0;
+        }
+        if (cv && st) store_chunk<G::TAIL>(out + 16 * c, res, G::TAIL != 0 && c == G::NCHUNK - 1);  // (cv: idle lanes share lines too)
+      };
+      own(0, p0, (u00 | u01) != 0, s0);
+      own(1, p1, (u10 | u11) != 0, s1);
+      own(2, p2, (u20 | u21) != 0, s2);
+      own(3, p3, (u30 | u31) != 0, s3);
     }
   } else {
-    // ---- dense factors: every candidate chunk by its own lane ----
-    if ((u00 | u01) != 0) finish(p0, lt, u00, u01);
-    if ((u10 | u11) != 0) finish(p1, lt + G::TSA, u10, u11);
-    if ((u20 | u21) != 0) finish(p2, lt + 2 * G::TSA, u20, u21);
-    if ((u30 | u31) != 0) finish(p3, lt + 3 * G::TSA, u30, u31);
+    // ---- dense factors: every candidate chunk by its own lane (16-byte stores in every variant) ----
+    auto direct = [&](int n, const uint4& pn, int uv0, int uv1) {
+      const int c = lt + G::TSA * n;
+      if ((uv0 | uv1) != 0) finish(pn, c, uv0, uv1);
+      else if (LINES && !inplace && active && c < G::NCHUNK) store_chunk<G::TAIL>(out + 16 * c, pn, G::TAIL != 0 && c == G::NCHUNK - 1);
+    };
+    direct(0, p0, u00, u01);
+    direct(1, p1, u10, u11);
+    direct(2, p2, u20, u21);
+    direct(3, p3, u30, u31);
   }
   const uint32_t both = block_or2((nz != 0 ? 1u : 0u) | (ovf != 0 ? 2u : 0u), or_slots);
   if (lt == 0) {

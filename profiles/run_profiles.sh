@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_graph_S16 -o 
 # 2. the same in eager mode (one ctypes launch per step)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_eager -o bench_eager -- python3 $R/bench.py --mode eager --steps 504 --warmup 56 --samples 3 $LEAN > $OUT/bench_eager.json 2> $OUT/bench_eager.err || exit 1
 # 3. HBM traffic counters, one pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass), eager, few steps
-for wl in "4 65536" "4 1048576" "4 4194304" "16 8192" "16 131072" "25 4096"; do
+for wl in "4 65536" "4 1048576" "4 4194304" "16 8192" "16 131072" "25 4096" "25 32768"; do
   set -- $wl
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_S$1_B$2_$ctr -o pmc -- python3 $R/bench.py --mode eager --steps 28 --warmup 14 --samples 2 --dim $1 --batch $2 $LEAN > $OUT/pmc_S$1_B$2_$ctr.json 2> $OUT/pmc_S$1_B$2_$ctr.err || exit 1

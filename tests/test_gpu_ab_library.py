@@ -146,10 +146,11 @@ def test_ab_switch_paths_stay_exact(env_name, tmp_path):
     _run(AB_SCRIPT, tmp_path, "AB_OK", {env_name: "1"})
 
 
-@pytest.mark.parametrize("env_name", ["TG_S16_LINES", "TG_S16_NT_LOADS", "TG_NO_S25_DIRECT", "TG_NO_S16_DIRECT", "TG_NO_S9_DIRECT"])
+@pytest.mark.parametrize("env_name", ["TG_S16_LINES", "TG_S16_NT_LOADS", "TG_S25_LINES", "TG_S25_NT_LOADS", "TG_NO_S25_DIRECT", "TG_NO_S16_DIRECT",
+                                      "TG_NO_S9_DIRECT"])
 def test_single_step_variants_stay_exact(env_name, tmp_path):
-    """The S=16 step with whole-line stores (the product takes it from 96 MiB of states on; forced here at small
-    batches) and with non-temporal state loads on top (from 384 MiB on), and the staged kernels that the direct S=9 / S=16 / S=25 step kernels replaced: sparse, dense (more candidate
+    """The S=16 / S=25 steps with whole-line stores (the product takes them from 96 MiB of states on; forced here at small
+    batches) and with non-temporal state loads on top (from 320 MiB on), and the staged kernels that the direct S=9 / S=16 / S=25 step kernels replaced: sparse, dense (more candidate
     rows than the queue holds), wide-factor, overflowing and null actions, in place and out of place."""
     _run(STEP_SCRIPT, tmp_path, "STEP_OK", {env_name: "1"})
 
