@@ -249,26 +249,34 @@ __global__ __launch_bounds__(kBlock) void hash_kernel(const int8_t* state, uint6
 // Rank of one S x S slice modulo BOTH primes at once: lanes 0..31 eliminate mod 2^26 - 5, lanes 32..63 the
 // same matrix mod 2^26 - 27 (S <= 32 rows per half-wave); the halves choose their own pivots.  Returns the
 // larger of the two ranks.
-template <int ST>
-__device__ __forceinline__ int slice_rank2(const int8_t* m, int S, int lane) {
+// W = rows per group (a power of two >= S, <= 32): a half-wave holds 32 / W slices side by side (S = 16: two,
+// S = 9: two, S = 4: eight), each group with its own pivots -- the lanes of a wavefront were 50 % idle at S = 16 and
+// 87 % at S = 4 with one slice per half.  Returns the sum of the ranks of the slices i0 .. i0 + 32 / W - 1 (those < S).
+template <int ST, int W>
+__device__ __forceinline__ int slice_rank2(const int8_t* game, int S, int i0, int lane) {
   constexpr int SMAX = ST ? ST : TG_MAX_S;
+  constexpr int GROUPS = 32 / W;
   const bool upper = lane >= 32;
-  const int r0 = lane & 31;
+  const int r0 = lane & (W - 1), grp = (lane & 31) / W;  // row within the slice, slice within the pass
+  const int slice = i0 + grp;
+  const bool mine_valid = r0 < S && slice < S;
+  const int8_t* m = game + (slice < S ? slice : 0) * S * S;
   const double P = upper ? 67108837.0 : 67108859.0;
   const double invP = upper ? (1.0 / 67108837.0) : (1.0 / 67108859.0);
   double row[SMAX];
 #pragma unroll
-  for (int c = 0; c < SMAX; ++c) row[c] = (r0 < S && c < S) ? static_cast<double>(m[r0 * S + c]) : 0.0;
-  bool used = r0 >= S;  // rows already chosen as pivots (and the idle lanes)
+  for (int c = 0; c < SMAX; ++c) row[c] = (mine_valid && c < S) ? static_cast<double>(m[r0 * S + c]) : 0.0;
+  bool used = !mine_valid;  // rows already chosen as pivots (and the idle lanes)
   int rank = 0;
+  const int gbase = lane & ~(W - 1);  // first lane of my group
 #pragma unroll
   for (int c = 0; c < SMAX; ++c) {
     if (c < S) {
       const uint64_t cand = __ballot(!used && row[c] != 0.0);
-      const uint32_t mine_half = upper ? static_cast<uint32_t>(cand >> 32) : static_cast<uint32_t>(cand);
-      if (cand) {  // wave-uniform; a half without a candidate just idles through the step
-        const bool has = mine_half != 0;
-        const int pr = (upper ? 32 : 0) + (has ? __builtin_ctz(mine_half) : 0);  // this half's pivot row
+      if (cand) {  // wave-uniform; a group without a candidate just idles through the step
+        const uint32_t gmask = static_cast<uint32_t>(cand >> gbase) & (W == 32 ? 0xFFFFFFFFu : ((1u << W) - 1u));
+        const bool has = gmask != 0;
+        const int pr = gbase + (has ? __builtin_ctz(gmask) : 0);  // this group's pivot row
         const double pc = __shfl(row[c], pr);
         const double mine = row[c];
         const bool upd = has && !used && lane != pr && mine != 0.0;
@@ -290,23 +298,34 @@ __device__ __forceinline__ int slice_rank2(const int8_t* m, int S, int lane) {
       }
     }
   }
-  const int r1 = __builtin_amdgcn_readlane(rank, 0), r2 = __builtin_amdgcn_readlane(rank, 32);
-  return r1 > r2 ? r1 : r2;
+  int total = 0;
+#pragma unroll
+  for (int q = 0; q < GROUPS; ++q) {  // per slice: the larger of the two primes' ranks
+    const int r1 = __builtin_amdgcn_readlane(rank, q * W), r2 = __builtin_amdgcn_readlane(rank, 32 + q * W);
+    total += r1 > r2 ? r1 : r2;
+  }
+  return total;
 }
 
 template <int ST>
 __global__ __launch_bounds__(kBlock) void rank_kernel(const int8_t* state, int32_t* out, int64_t B, int Srt,
                                                       int64_t stride) {
   __shared__ int partial[kBlock / 64];
+  constexpr int W = ST == 0 ? 32 : (ST <= 4 ? 4 : (ST <= 8 ? 8 : (ST <= 16 ? 16 : 32)));
+  constexpr int GROUPS = 32 / W;
   const int S = ST ? ST : Srt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // one workgroup per game: its 4 wavefronts walk the S slices
+  if constexpr (ST != 0 && ST <= GROUPS) {  // S = 4: one pass of one wavefront is a whole game -- a wavefront per game
+    for (int64_t g = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave; g < B; g += static_cast<int64_t>(gridDim.x) * (kBlock / 64)) {
+      const int t = slice_rank2<ST, W>(state + g * stride, S, 0, lane);
+      if (lane == 0) out[g] = t;
+    }
+    return;
+  }
+  // one workgroup per game: its 4 wavefronts walk the S slices, 32 / W at a time
   for (int64_t g = blockIdx.x; g < B; g += gridDim.x) {
     int acc = 0;
-    for (int i = wave; i < S; i += kBlock / 64) {
-      const int8_t* m = state + g * stride + i * S * S;
-      acc += slice_rank2<ST>(m, S, lane);
-    }
+    for (int i = wave * GROUPS; i < S; i += (kBlock / 64) * GROUPS) acc += slice_rank2<ST, W>(state + g * stride, S, i, lane);
     if (lane == 0) partial[wave] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -412,7 +431,7 @@ int tg_rank_i32(const int8_t* state, int32_t* rank_out, int64_t B, int S, int64_
   if (int rc = check_state(fn, B, S, game_stride_bytes)) return rc;
   if (B == 0) return TG_OK;
   if (!state || !rank_out) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
-  const dim3 grid(grid_for(B, 1 << 20)), block(tg::kBlock);
+  const dim3 grid(grid_for(S == 4 ? (B + 3) / 4 : B, 1 << 20)), block(tg::kBlock);  // (S = 4: a wavefront per game)
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();
   switch (S) {
