@@ -53,11 +53,13 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 INFINITY_CACHE_BYTES = 256 << 20
-STEP_KERNEL = {4: "tg::s4_kernel<0>", 9: "tg::s9_step_kernel<0>"}
+STEP_KERNEL = {9: "tg::s9_step_kernel<0>"}
 
 
 def step_kernel_name(S: int, B: int) -> str:
     """The kernel tg_step_i8 launches for aligned int8 states (tg_kernels.hip, apply_launch)."""
+    if S == 4:  # non-temporal state loads from 96 MiB of states on
+        return "tg::s4_kernel<0, true>" if B * 64 >= (96 << 20) else "tg::s4_kernel<0, false>"
     if S == 16:  # whole-line stores from 96 MiB of states on, non-temporal state loads from 320 MiB on
         if B * 4096 >= (320 << 20):
             return "tg::s16_step_kernel<0, true, true>"

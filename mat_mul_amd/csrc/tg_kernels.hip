@@ -518,7 +518,7 @@ __device__ __forceinline__ uint4 s4_step_slice(const uint4 in_slice, uint32_t du
   return pk;
 }
 
-template <int MODE>
+template <int MODE, bool NTL = false>
 __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
   // Addressing: everything that depends on blockIdx is SCALAR 64-bit math (SALU); the per-lane
   // part is a small 32-bit offset (host guarantees strides < 2^20).  At the BASELINE cfg2 shape
@@ -534,7 +534,14 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
   const int8_t* in_blk = a.in + g0 * a.in_stride;
   const uint32_t in_off = __umul24(lg, static_cast<uint32_t>(a.in_stride)) + 16u * q;
   uint4 pk{0, 0, 0, 0};
-  if constexpr (MODE != GENF) pk = *reinterpret_cast<const uint4*>(in_blk + in_off);
+  if constexpr (MODE != GENF) {
+    if constexpr (NTL) {  // (batches beyond the Infinity Cache: see s16_step_kernel)
+      const v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(in_blk + in_off));
+      pk = uint4{v.x, v.y, v.z, v.w};
+    } else {
+      pk = *reinterpret_cast<const uint4*>(in_blk + in_off);
+    }
+  }
   int ovf = 0;
 
   if constexpr (MODE == STEP || MODE == STEPS || MODE == MANY || MODE == GENF) {
@@ -1286,6 +1293,7 @@ __global__ __launch_bounds__(kBlock) void matmul_template_kernel(int8_t* dst, in
 // dst[b] <- src[b] for b < B: one thread per 16-byte chunk of a game (the mapping of the step kernels without
 // their arithmetic), grid = all chunks.  SH >= 0: chunks per game = 1 << SH (S = 4, 8, 16: shifts instead of a
 // division).  The padding between games is neither read nor written.  vec16 == 0: byte granularity.
+template <int NT>
 __global__ __launch_bounds__(kBlock) void copy_kernel(const int8_t* src, int8_t* dst, int64_t B, int nchunk, int sh,
                                                       int tailb, int64_t sstride, int64_t dstride) {
   const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -1304,7 +1312,16 @@ __global__ __launch_bounds__(kBlock) void copy_kernel(const int8_t* src, int8_t*
   if (tailb != 0 && c == nchunk - 1) {  // the game's last chunk holds only tailb bytes
     for (int t = 0; t < tailb; ++t) d[t] = s[t];
   } else {
-    *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+    // (NT as a template parameter: behind a run-time flag hipcc merges the two loads / stores into a plain one)
+    uint4 q;
+    if constexpr (NT >= 1) {
+      const v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(s));
+      q = uint4{v.x, v.y, v.z, v.w};
+    } else {
+      q = *reinterpret_cast<const uint4*>(s);
+    }
+    if constexpr (NT == 2) store16_nt(d, q);
+    else *reinterpret_cast<uint4*>(d) = q;
   }
 }
 
@@ -1432,7 +1449,17 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
         return check_launch(fn);
       }
     }
-    (void)hipGetLastError(); hipLaunchKernelGGL((s4_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+    (void)hipGetLastError();
+    if constexpr (MODE == STEP) {
+      // Non-temporal state loads from 96 MiB of states on (in place, measured: 64 MiB 23.1 / 24.0 us plain / nt,
+      // 128 MiB 48.6 / 44.9, 192 MiB 71.8 / 65.1, 256 MiB 92.4 / 85.4, 512 MiB 205 / 204): the lines a launch reads
+      // are not worth their place in the Infinity Cache when the next launch's reads evict them anyway.
+      if ((B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S4_NT_LOADS")) && !TG_SWITCH("TG_S4_NO_NT_LOADS")) {
+        hipLaunchKernelGGL((s4_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+        return check_launch(fn);
+      }
+    }
+    hipLaunchKernelGGL((s4_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
     return check_launch(fn);
   }
   // packed int16 path: exact while nact * f^3 <= 32000 for every |factor| <= f (checked on device)
@@ -1861,8 +1888,19 @@ int tg_copy_i8(const int8_t* state_in, int8_t* state_out, int64_t B, int S, int6
       if ((1 << t) == nchunk) sh = t;
     const int64_t blocks = (B * nchunk + tg::kBlock - 1) / tg::kBlock;
     if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "tg_copy_i8: B too large");
-    hipLaunchKernelGGL(tg::copy_kernel, dim3((unsigned)blocks), dim3(tg::kBlock), 0, st, state_in, state_out, B, nchunk,
-                       sh, N % 16, in_stride_bytes, out_stride_bytes);
+    // Out of place, by the bytes both buffers hold together (measured, tg_copy_i8 ping-pong between two buffers, plain /
+    // nt loads / nt loads + stores): 256 MiB 33 / 34 / 41 us, 384 MiB 67 / 49 / 61, 512 MiB 88 / 71 / 81, 768 MiB
+    // 131 / 127 / 120, 1 GiB 172 / 167 / 160.  This kernel is the bench's copy ceiling: it has to be the best copy.
+    const int64_t both = state_in == state_out ? 0 : B * (in_stride_bytes + out_stride_bytes);
+    if (both > (640ll << 20) || TG_SWITCH("TG_COPY_NT2"))
+      hipLaunchKernelGGL(tg::copy_kernel<2>, dim3((unsigned)blocks), dim3(tg::kBlock), 0, st, state_in, state_out, B, nchunk,
+                         sh, N % 16, in_stride_bytes, out_stride_bytes);
+    else if (both > (256ll << 20) || TG_SWITCH("TG_COPY_NT1"))
+      hipLaunchKernelGGL(tg::copy_kernel<1>, dim3((unsigned)blocks), dim3(tg::kBlock), 0, st, state_in, state_out, B, nchunk,
+                         sh, N % 16, in_stride_bytes, out_stride_bytes);
+    else
+      hipLaunchKernelGGL(tg::copy_kernel<0>, dim3((unsigned)blocks), dim3(tg::kBlock), 0, st, state_in, state_out, B, nchunk,
+                         sh, N % 16, in_stride_bytes, out_stride_bytes);
   } else {
     hipLaunchKernelGGL(tg::copy_bytes_kernel, dim3(capped_grid(B > 65536 ? 65536 : B)), dim3(tg::kBlock), 0, st, state_in,
                        state_out, B, N, in_stride_bytes, out_stride_bytes);

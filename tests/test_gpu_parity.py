@@ -582,7 +582,8 @@ def test_basis(S):
                                    (4, 131072, 7), (4, 1 << 20, 7),    # cfg4: per-GPU share at 8 GPUs, and whole
                                    (16, 32768, 12), (9, 262144, 6),    # S=16 with whole-line stores (128 MiB); S=9 streaming
                                    (16, 98304, 5),                     # S=16 beyond the cache (384 MiB of states): non-temporal state loads
-                                   (25, 8192, 6), (25, 26000, 4)])     # S=25 with whole-line stores (122 MiB) / + non-temporal loads (388 MiB)
+                                   (25, 8192, 6), (25, 26000, 4),      # S=25 with whole-line stores (122 MiB) / + non-temporal loads (388 MiB)
+                                   (4, 1 << 21, 4)])                   # S=4 beyond 96 MiB: non-temporal state loads
 def test_full_size_generate_replay_terminate(S, B, R):
     """cfg2/cfg3/cfg4/cfg5-per-GPU: generator -> replay the demo's own actions -> every game reaches
     zero exactly at the last step (generator, step, step_many and done agree)."""
