@@ -18,11 +18,13 @@ namespace tg {
 
 constexpr int kBlock = 256;  // 4 wavefronts of 64
 
-// Non-temporal 16-byte store, for the children of tg_expand_i8 at S = 4 (tools/expand_probe.hip, 2^20 parents x 8
-// children, 537 MB written: 146 us with plain stores, 97 us with nt stores; the product kernel 163 -> 110 us).
-// Measured and NOT adopted elsewhere: in-place streams gain nothing (78.2 / 78.1 us at 4 M games), the model-input
-// frames lose (f16, 2^20 games: 156 -> 175 us), S = 25 children lose (124 -> 136 us: 15 625-byte children end in
-// partial lines), S = 16 children are unchanged (56.5 / 57.1 us; NOTES.md: three forms of that kernel, same time).
+// Non-temporal 16-byte store, for pure write streams: the children of tg_expand_i8 at S = 4 and S = 16
+// (tools/expand_probe.hip, 2^20 parents x 8 children, 537 MB written: 146 us with plain stores, 97 us with nt stores;
+// the product kernels 163 -> 110 us at S = 4, 56.5 -> 50.6 us at S = 16) and the model-input frames (tg_aux.hip).
+// Not for S = 25 children (124 -> 134 us: 15 625-byte children end in partial lines) and not for in-place streams (S = 4,
+// 4 M games: 78.2 / 78.1 us) -- those gain from non-temporal LOADS instead (s4_kernel, s16_step_kernel, s25_step_kernel).
+// ALWAYS select it by a template parameter: behind a run-time flag hipcc merges the two stores into a plain one, and an
+// A/B run then measures nothing (that happened to the first round of these experiments).
 typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16_nt(void* p, const uint4& q) {
   __builtin_nontemporal_store(v4u_t{q.x, q.y, q.z, q.w}, reinterpret_cast<v4u_t*>(p));

@@ -62,7 +62,7 @@ struct ApplyArgs {
   int nact;
   int shift;
   int only_flagged;      // MANY: redo only the games whose done_step is kNeedsExact (second pass after tg_mfma.h)
-  int stream_out;        // EXPAND, S = 4: the children leave by non-temporal stores (output beyond kStreamOutBytes)
+  int stream_out;        // EXPAND, S = 4 / 16: the children leave by non-temporal stores (output beyond kStreamOutBytes)
 };
 
 // done_step value by which many_mfma_kernel hands a game to the lattice kernels (never a valid result)
@@ -1639,6 +1639,17 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
     // S=9: a game is only 46 chunks, so a wavefront takes FOUR games (teams of 16 lanes, 9 active, 6
     // chunks per lane): measured 0.48 of the HBM peak at 2^19 games against 0.43 (TS=32) and 0.29 (TS=64)
     if (a.S == 9) TG_PACKED(9, 16);
+    if constexpr (MODE == EXPAND) {
+      if (a.S == 16 && a.stream_out) {  // children of 128 MiB and more: non-temporal stores
+        const int64_t blocks = (B + PGeo<16, 64>::GPB - 1) / PGeo<16, 64>::GPB;
+        if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
+        const int at = a.nact < PGeo<16, 64>::ATILE ? a.nact : PGeo<16, 64>::ATILE;
+        const int ldsb = packed_lds_bytes<16, 64, MODE>(at);
+        (void)hipGetLastError();
+        hipLaunchKernelGGL((packed_kernel<16, 64, MODE, true>), dim3((unsigned)blocks), dim3(kBlock), ldsb, st, a, flim, at);
+        return check_launch(fn);
+      }
+    }
     if (a.S == 16) TG_PACKED(16, 64);
     if (a.S == 25) TG_PACKED(25, 256);
   }

@@ -197,7 +197,9 @@ constexpr int packed_lds_bytes(int at) {
   return ((tables + raw + ((nflag + 3) & ~3) + 15) & ~15) + 32;  // + two 16-byte slot arrays of block_or2
 }
 
-template <int S, int TS, int MODE>
+// NTS (EXPAND at S = 16 only): the children leave by non-temporal stores (268 MB of children: 56.5 -> 50.6 us; the
+// 15 625-byte children of S = 25 end in partial lines and lose with them: 124 -> 134 us).
+template <int S, int TS, int MODE, bool NTS = false>
 __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, int at) {
   using G = PGeo<S, TS>;
   constexpr bool SUB = (MODE != GENF);  // STEP, STEPS, MANY, EXPAND subtract
@@ -583,7 +585,11 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
         for (int n = 0; n < G::NCH; ++n) {
           const uint4 q = pack_pairs(A[n], nz, covf);
           if (live && cv[n])
-            store_chunk<G::TAIL>(a.out + child * a.out_stride + 16 * (lt + G::TSA * n), q, ctail[n]);
+          {
+            int8_t* const dp = a.out + child * a.out_stride + 16 * (lt + G::TSA * n);
+            if constexpr (NTS && G::TAIL == 0) store16_nt(dp, q);
+            else store_chunk<G::TAIL>(dp, q, ctail[n]);
+          }
         }
         if (nz) nzF[k] = 1;
         if (covf & 0xFF00FF00u) ovF[k] = 1;
