@@ -423,7 +423,10 @@ int tg_hash_u64(const int8_t* state, uint64_t* hash_out, int64_t B, int S, int64
   const int N = S * S * S;
   const int vec16 = (reinterpret_cast<uintptr_t>(state) & 15) == 0 && game_stride_bytes % 16 == 0;
   int lpg = 1;
-  while (lpg < 64 && lpg * 16 < N) lpg <<= 1;
+  // lanes per game: up to four 16-byte chunks per lane for games of 16 chunks and more (S=9: 16 lanes x 3 chunks, four
+  // games per wavefront -- with a wavefront per game 46 lanes did one load each and the launch was latency-bound:
+  // 12-16 us for 24 MB), one chunk per lane for the small ones (S=4: 4 lanes)
+  while (lpg < 64 && lpg * 16 * (N >= 256 ? 4 : 1) < N) lpg <<= 1;
   const int64_t blocks = (B * lpg + tg::kBlock - 1) / tg::kBlock;
   (void)hipGetLastError();
   hipLaunchKernelGGL(tg::hash_kernel, dim3(grid_for(blocks, 8192)), dim3(tg::kBlock), 0,

@@ -1927,7 +1927,10 @@ int tg_done_i8(const int8_t* state, uint8_t* done, int32_t* nnz, int64_t B, int 
   const int vec16 = aligned16(state) && game_stride_bytes % 16 == 0;
   const int N = S * S * S;
   int lpg = 1;
-  while (lpg < 64 && lpg * 16 < N) lpg <<= 1;  // lanes per game: one 16-byte chunk each where possible
+  // lanes per game: up to four 16-byte chunks per lane for games of 16 chunks and more (S=9: 16 lanes x 3 chunks, four
+  // games per wavefront -- with a wavefront per game 46 lanes did one load each and the launch was latency-bound:
+  // 12-16 us for 24 MB), one chunk per lane for the small ones (S=4: 4 lanes)
+  while (lpg < 64 && lpg * 16 * (N >= 256 ? 4 : 1) < N) lpg <<= 1;
   const int64_t blocks = (B * lpg + tg::kBlock - 1) / tg::kBlock;
   (void)hipGetLastError(); hipLaunchKernelGGL(tg::done_kernel, dim3(capped_grid(blocks > 8192 ? 8192 : blocks)), dim3(tg::kBlock), 0,
                      static_cast<hipStream_t>(stream), state, done, nnz, B, N, game_stride_bytes, vec16, lpg);
