@@ -52,7 +52,24 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_ACHIEVABLE_GBS = 6300.0  # the same guide: what a streaming kernel reaches on a footprint far beyond the caches
+L2_BYTES = 32 << 20  # 8 XCDs x 4 MiB
 INFINITY_CACHE_BYTES = 256 << 20
+HBM_REGIME_BYTES = 2 << 30  # from here on the Infinity Cache holds an eighth of the footprint at most
+
+
+def regime_of(footprint):
+    """(regime label, bound) of a launch by the bytes of state it sweeps.  Only footprints of 2 GiB and more are
+    priced as HBM streams: up to 1-2 GiB the 256 MiB Infinity Cache still serves a visible share of an in-place
+    ping-pong (round 2 measured 6.9-7.8 TB/s of 'HBM' traffic on 256-512 MiB, more than HBM delivers alone)."""
+    mib = footprint / 2 ** 20
+    if footprint < L2_BYTES:
+        return "L2-resident: %.0f MiB of states < 32 MiB of L2; the launch boundary dominates, HBM is not exercised" % mib, "launch"
+    if footprint < INFINITY_CACHE_BYTES:
+        return "Infinity-Cache-resident: %.0f MiB of states < 256 MiB; HBM is not exercised" % mib, "cache"
+    if footprint < HBM_REGIME_BYTES:
+        return "cache-assisted: %.0f MiB of states, 1-8x the Infinity Cache, which still serves part of every pass" % mib, "cache"
+    return "hbm-streaming: %.0f MiB of states per launch, >= 8x the Infinity Cache" % mib, "hbm"
 STEP_KERNEL = {9: "tg::s9_step_kernel<0>"}
 
 
@@ -77,12 +94,13 @@ def bytes_step(S: int) -> int:
 
 
 # ------------------------------------------------------------------------------------------- workloads
-def make_demo_schedule(B, S, R, dev, seed, gid0):
+def make_demo_schedule(B, S, R, dev, seed, gid0, pad_to=16):
     """Start state + 2R token tensors: the demo's own R actions, then the same actions with u negated (which add
     the terms back).  After R steps every game is zero; after 2R it is back at its start."""
     from mat_mul_amd import ops
 
-    actions, target = ops.gen_demos(B, S, R, dev, seed=seed, game_id_offset=gid0)
+    actions, target = ops.gen_demos(B, S, R, dev, seed=seed, game_id_offset=gid0,
+                                    target=ops.alloc_states(B, S, dev, pad_to=pad_to, zero=False))
     sched = []
     for k in range(R):
         sched.append(actions[:, k].contiguous())
@@ -143,14 +161,14 @@ def needed_bytes_per_launch(B, S, sched, inplace=True):
 class StepTimer:
     """W warm-up launches, then `samples` samples of exactly K chained in-place tg_step_i8 launches."""
 
-    def __init__(self, state0, sched, dev, mode="graph", shift=1):
+    def __init__(self, state0, sched, dev, mode="graph", shift=1, pad_to=16):
         from mat_mul_amd import ops
 
         self.dev, self.mode, self.sched, self.L = dev, mode, sched, len(sched)
         B, S = state0.shape[0], state0.shape[1]
         self.B, self.S = B, S
         self.start = state0
-        self.state = ops.alloc_states(B, S, dev)
+        self.state = ops.alloc_states(B, S, dev, pad_to=pad_to)
         self.state.copy_(state0)
         self.done = torch.zeros(B, dtype=torch.uint8, device=dev)
         self.ovf = torch.zeros(B, dtype=torch.uint8, device=dev)
@@ -275,12 +293,12 @@ class StepTimer:
                 "run_ms_with_lead_in": replay_ms, "run_ms_lead_in_only": [t[2 * i + 1] for i in range(samples)]}
 
 
-def copy_ceiling_gbps(B, S, dev, K=64, samples=5):
+def copy_ceiling_gbps(B, S, dev, K=64, samples=5, pad_to=16):
     """A copy kernel of the same footprint in the same run: K chained tg_copy_i8 launches (ping-pong between two
     state buffers) replayed as a hipGraph; GB/s = 2 * S^3 * B bytes per launch / median launch time."""
     from mat_mul_amd import ops
 
-    a, b = ops.alloc_states(B, S, dev), ops.alloc_states(B, S, dev)
+    a, b = ops.alloc_states(B, S, dev, pad_to=pad_to), ops.alloc_states(B, S, dev, pad_to=pad_to)
     ops.copy_states(a, b)
     cur = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(device=dev)
@@ -320,7 +338,20 @@ def measured_traffic(B, S, kernel):
     return None, None
 
 
-def roofline(B, S, K, event_ms_samples, needed_bytes=None, copy=None, footprint=None, res=None):
+_HBM_COPY = {}
+
+
+def hbm_copy_ceiling(dev):
+    """GB/s of tg_copy_i8 between two 2 GiB buffers (S=4 layout), measured once per run: what an out-of-place stream
+    reaches on THIS box when the caches cannot help -- the achievable figure beside the 8 TB/s spec peak."""
+    key = str(dev)
+    if key not in _HBM_COPY:
+        _HBM_COPY[key] = copy_ceiling_gbps(1 << 25, 4, dev, K=6, samples=3)
+        torch.cuda.empty_cache()
+    return _HBM_COPY[key]
+
+
+def roofline(B, S, K, event_ms_samples, needed_bytes=None, copy=None, footprint=None, res=None, hbm_copy=None):
     """The roofline object of one workload.  `frac` = needed bytes / median launch time / HBM peak: the bytes the
     launch must move (never more than SURVEY's algorithmic figure), so it cannot be inflated by stores the kernel
     skips; `frac_algorithmic` prices SURVEY's 2S^3+3S+1 unconditionally and CAN exceed what the memory system
@@ -331,7 +362,8 @@ def roofline(B, S, K, event_ms_samples, needed_bytes=None, copy=None, footprint=
     kernel = step_kernel_name(S, B)
     traffic, tround = measured_traffic(B, S, kernel)
     footprint = footprint if footprint is not None else B * (-(-S ** 3 // 16) * 16)
-    out = {"bound": "hbm", "achieved": round(need / per_launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    regime, bound = regime_of(footprint)
+    out = {"bound": bound, "achieved": round(need / per_launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(need / per_launch_s / 1e9 / HBM_PEAK_GBS, 4),
            "frac_algorithmic": round(alg / per_launch_s / 1e9 / HBM_PEAK_GBS, 4),
            "frac_traffic": round(traffic / per_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
@@ -339,9 +371,13 @@ def roofline(B, S, K, event_ms_samples, needed_bytes=None, copy=None, footprint=
            "bytes_per_launch": alg, "needed_bytes_per_launch": int(round(need)),
            "avg_launch_us": round(per_launch_s * 1e6, 3),
            "launch_us_samples": [round(x * 1e3 / K, 3) for x in event_ms_samples],
-           "regime": ("cache-resident: %.0f MiB of states < 256 MiB Infinity Cache, HBM itself is not exercised"
-                      % (footprint / 2 ** 20)) if footprint < INFINITY_CACHE_BYTES
-           else "hbm-streaming: %.0f MiB of states per launch" % (footprint / 2 ** 20),
+           "regime": regime,
+           "bound_note": {"launch": "priced against the HBM peak as the contract asks, but bound by the dependent-launch "
+                                    "boundary (an empty kernel costs 1.55 us per launch on this chip)",
+                          "cache": "priced against the HBM peak; the bytes come from the caches, so this is a "
+                                   "throughput, not an HBM-roofline fraction",
+                          "hbm": "an HBM stream: peak = the 8 TB/s spec figure; hbm_copy_ceiling_GBps = the copy of a "
+                                 "2 GiB buffer measured in this run (the guide quotes ~6.3 TB/s achievable)"}[bound],
            "method": "HIP events on the launch stream, no host sync inside the pass: per sample T(run of m lead-in + K "
                      "launches) - T(run of m launches), median over the samples, / K -- the fixed cost of a hipGraph "
                      "replay (~13 us, runtime submit) cancels; frac = needed bytes per launch / that time / peak"}
@@ -355,6 +391,11 @@ def roofline(B, S, K, event_ms_samples, needed_bytes=None, copy=None, footprint=
     if copy is not None:
         out["copy_ceiling_GBps"], out["copy_launch_us"] = copy
         out["frac_of_copy_ceiling"] = round(out["achieved"] / copy[0], 4) if copy[0] else None
+    if hbm_copy is not None:
+        out["hbm_copy_ceiling_GBps"] = hbm_copy[0]
+        out["hbm_achievable_GBps_guide"] = HBM_ACHIEVABLE_GBS
+        if bound == "hbm":
+            out["frac_of_hbm_copy_ceiling"] = round(out["achieved"] / hbm_copy[0], 4) if hbm_copy[0] else None
     return out
 
 
@@ -521,8 +562,11 @@ def main(argv=None):
     start, sched, _ = make_demo_schedule(B, S, R, dev, 0, lo)
     tm = StepTimer(start, sched, dev, args.mode)
     res = tm.measure(args.steps, args.warmup, args.samples, sync=group.barrier)
-    reduced = group.max_over_ranks(*res["wall_s"], 0.0 if res["ok"] else 1.0)
-    walls, bad = list(reduced[:-1]), reduced[-1]
+    # per rank: the event-timed launch time and the fixed cost of one graph replay; MAX over ranks of both
+    my_launch_us = statistics.median(res["event_ms"]) * 1e3 / args.steps
+    my_fixed_us = statistics.median(res["run_ms_lead_in_only"]) * 1e3 - res["lead_in"] * my_launch_us
+    reduced = group.max_over_ranks(*res["wall_s"], 0.0 if res["ok"] else 1.0, my_launch_us, my_fixed_us)
+    walls, bad, launch_us_max, fixed_us_max = list(reduced[:-3]), reduced[-3], reduced[-2], reduced[-1]
     if bad:
         raise SystemExit("bench self-check failed: the state did not return to its start after full cycles")
 
@@ -530,6 +574,7 @@ def main(argv=None):
         wall = statistics.median(walls)
         need = needed_bytes_per_launch(B, S, sched)
         copy = copy_ceiling_gbps(B, S, dev)
+        hbm_copy = hbm_copy_ceiling(dev) if world == 1 and not args.no_also else None
         out = {
             "metric": "env steps/sec (batched games)", "value": round(G * args.steps / wall, 1), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "samples": args.samples,
@@ -541,8 +586,16 @@ def main(argv=None):
                        "timing": f"{args.samples} samples of exactly {args.steps} steps, each bracketed by barrier + "
                                  f"synchronize, max over ranks per sample, median over samples",
                        "wall_us_per_sample": [round(w * 1e6, 1) for w in walls]},
-            "roofline": roofline(B, S, args.steps, res["event_ms"], need, copy, res=res),
+            "roofline": roofline(B, S, args.steps, res["event_ms"], need, copy, res=res, hbm_copy=hbm_copy),
         }
+        if world > 1:
+            # what a --steps 20 wall clock hides: every timed sample is ONE hipGraph replay, whose fixed submit cost
+            # (~13 us on ROCm 7.2) is paid once per sample whatever the batch -- so the wall-clock speed-up of a
+            # strong-scaling run understates the kernels'.  Both are reported; the kernels' from HIP events, MAX over ranks.
+            out["per_rank"] = {"event_launch_us_max_over_ranks": round(launch_us_max, 3),
+                               "graph_replay_fixed_cost_us_max_over_ranks": round(fixed_us_max, 2),
+                               "event_steps_per_s": round(G / (launch_us_max * 1e-6), 1),
+                               "wall_us_per_step": round(wall * 1e6 / args.steps, 3)}
         if world > 1 and scaling == "strong" and not args.no_also:
             # the same GLOBAL batch on ONE GPU (rank 0 alone, after the timed region): the denominator of the
             # strong-scaling speedup, measured in the same run
@@ -554,11 +607,20 @@ def main(argv=None):
             out["single_gpu_same_global_batch"] = {
                 "ok": r1["ok"], "value": round(G * k1 / w1, 1), "unit": "steps/s", "steps": k1,
                 "roofline": roofline(G, S, k1, r1["event_ms"], needed_bytes_per_launch(G, S, sc1))}
+            one_us = out["single_gpu_same_global_batch"]["roofline"]["avg_launch_us"]
+            fixed1 = statistics.median(r1["run_ms_lead_in_only"]) * 1e3 - r1["lead_in"] * one_us
+            # the driver's own clock sees (K launches + one replay) per sample on both sides of the ratio
+            out["speedup_vs_single"] = {
+                "event": round(one_us / launch_us_max, 3),
+                "wall_at_these_steps": round((args.steps * one_us + fixed1) / (wall * 1e6), 3),
+                "wall_model": "T1 = steps x the single-GPU launch time + its replay cost, over the measured N-GPU wall time of a sample",
+                "single_gpu_launch_us": one_us, "single_gpu_replay_fixed_cost_us": round(fixed1, 2),
+                "ideal": world}
             del t1, s1, sc1
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(G, S)
         if world == 1 and not args.no_also:
-            out["also"] = also_lines(S, G, dev, args.mode)
+            out["also"] = also_lines(S, G, dev, args.mode, hbm_copy)
             # BASELINE's metric names S=4 and S=16: surface config 3 at the top level as well
             for a3 in out["also"]:
                 if a3["workload"].startswith("S=16 batch=8192 (BASELINE config 3)"):
@@ -571,7 +633,7 @@ def main(argv=None):
     return 0
 
 
-def also_lines(S_main, B_main, dev, mode):
+def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
     """The other single-GPU workloads (informational; every line carries its own self-check)."""
     from mat_mul_amd import ops
 
@@ -582,10 +644,13 @@ def also_lines(S_main, B_main, dev, mode):
             (16, 8192, 512, "SURVEY 8(d) dense inputs: uniform {-2..2} states, every 97th game terminal", "dense"),
             (4, 1 << 17, 1008, "BASELINE config 4 per-GPU share at 8 GPUs", "demo"),
             (4, 1 << 20, 112, "BASELINE config 4 on ONE GPU (67 MB of states)", "demo"),
-            (4, 1 << 22, 112, "HBM-streaming batch (268 MB of states)", "demo"),
+            (4, 1 << 22, 112, "cache-assisted batch (256 MiB of states = the Infinity Cache)", "demo"),
             (25, 4096, 208, "config 5 per-GPU step", "demo"),
-            (16, 1 << 17, 64, "HBM-streaming batch (537 MB of states)", "demo"),
-            (25, 1 << 15, 64, "BASELINE config 5 whole on ONE GPU (512 MB of states, streams from HBM)", "demo")]:
+            (16, 1 << 17, 64, "cache-assisted batch (512 MiB of states)", "demo"),
+            (25, 1 << 15, 64, "BASELINE config 5 whole on ONE GPU (488 MiB of states, cache-assisted)", "demo"),
+            (4, 1 << 25, 16, "HBM stream: 2 GiB of states", "demo"),
+            (16, 1 << 19, 16, "HBM stream: 2 GiB of states", "demo"),
+            (25, 1 << 17, 16, "HBM stream: 1.9 GiB of states", "demo")]:
         if kind == "demo" and s2 == S_main and b2 == B_main:
             continue
         if kind == "demo":
@@ -601,13 +666,18 @@ def also_lines(S_main, B_main, dev, mode):
             want[info["planted"]] = 1
             extra_ok = bool(torch.equal(tm.done, want))
             tm.eager(1)
-        r2 = tm.measure(k2, 32, 5)
+        huge = b2 * s2 ** 3 >= (1 << 30)
+        r2 = tm.measure(k2, 8 if huge else 32, 3 if huge else 5)
         w2 = statistics.median(r2["wall_s"])
+        need2 = needed_bytes_per_launch(b2, s2, sc)
+        del tm
         also.append({"workload": f"S={s2} batch={b2} ({label})", "ok": r2["ok"] and extra_ok,
                      "value": round(b2 * k2 / w2, 1), "unit": "steps/s", "steps": k2,
-                     "roofline": roofline(b2, s2, k2, r2["event_ms"], needed_bytes_per_launch(b2, s2, sc),
-                                          copy_ceiling_gbps(b2, s2, dev, K=16 if b2 * s2 ** 3 > (1 << 27) else 64))})
-        del tm, st, sc
+                     "roofline": roofline(b2, s2, k2, r2["event_ms"], need2,
+                                          copy_ceiling_gbps(b2, s2, dev, K=6 if huge else (16 if b2 * s2 ** 3 > (1 << 27) else 64),
+                                                            samples=3 if huge else 5), hbm_copy=hbm_copy)})
+        del st, sc
+        torch.cuda.empty_cache()
     # the fused path, labelled separately: K actions per launch, state stays on chip
     for (s2, b2, k2) in [(4, 65536, 7), (16, 8192, 20), (25, 4096, 64)]:
         tok, tgt = ops.gen_demos(b2, s2, k2, dev, seed=2)

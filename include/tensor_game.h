@@ -125,6 +125,14 @@ int tg_expand_i8(const int8_t* state_in, int8_t* state_out, const int8_t* action
                  uint8_t* changed, uint8_t* overflow, int64_t B, int S, int k,
                  int64_t in_stride_bytes, int64_t out_stride_bytes, int shift, tg_stream_t stream);
 
+/* tg_expand_i8 that also returns keys_out[b*k+i] (uint64 (B,k), 8-byte aligned; NULL = tg_expand_i8) = the
+ * tg_hash_u64 key of child (b,i): what extend_tree computes per child with state_to_str (act.py:188-190) before it
+ * tests the tree (tg_seen_u64).  At S = 4 the key is formed while the child is in registers; other sizes run the key
+ * kernel over the children inside the same call. */
+int tg_expand_keyed_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions, uint8_t* done,
+                       uint8_t* changed, uint8_t* overflow, uint64_t* keys_out, int64_t B, int S, int k,
+                       int64_t in_stride_bytes, int64_t out_stride_bytes, int shift, tg_stream_t stream);
+
 /* done[b] = (state[b] == 0 everywhere); nnz[b] (int32, may be NULL) = number of non-zero entries.
  * Replaces tensor_factorized (utils.py:181-188) per game and the nnz bound of training.py:266. */
 int tg_done_i8(const int8_t* state, uint8_t* done, int32_t* nnz, int64_t B, int S,
@@ -211,9 +219,23 @@ int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_dtype,
 int tg_hash_u64(const int8_t* state, uint64_t* hash_out, int64_t B, int S,
                 int64_t game_stride_bytes, tg_stream_t stream);
 
+/* N2, second half: the transposition table.  extend_tree keeps only the children whose key is not yet a key of the
+ * tree (`c not in new_mc_tree`, act.py:188-195) and then records the expanded state's key (act.py:209-211).  `table`
+ * is a caller-owned open-addressing array of uint64, `capacity` (a power of two) entries, zero-initialised = empty
+ * (hipMemset); linear probing from key & (capacity-1); a key equal to 0 is stored as 0x9E3779B97F4A7C15.  Keep the
+ * load factor at or below one half.
+ *   fresh[i] (uint8, may be NULL when insert != 0) = 1 iff mask[i] != 0 and keys[i] was not in the table BEFORE this
+ *   call (so equal keys inside one call are all fresh, like the reference's list comprehension); mask (uint8 (n), may
+ *   be NULL = all ones) is typically `changed` of tg_expand_i8, which makes fresh = "not a null action and not yet in
+ *   the tree".  insert != 0: afterwards every masked key is in the table (lookup and insertion are two kernels of the
+ *   same call, in that order).  status (uint32 (1), may be NULL): bit 0 is SET when a key could not be recorded because
+ *   the table is full.  keys and table must be 8-byte aligned. */
+int tg_seen_u64(const uint64_t* keys, uint64_t* table, int64_t capacity, uint8_t* fresh, const uint8_t* mask,
+                uint32_t* status, int64_t n, int insert, tg_stream_t stream);
+
 /* N3, terminal reward.  rank_out[b] (int32) = sum over the S slices state[b][i] of the rank of the
- * S x S integer matrix, computed exactly over GF(p) for the two primes 2^31-1 and 2^31-19 (the
- * maximum is taken; it equals the rational rank unless a minor is divisible by both primes).
+ * S x S integer matrix, computed exactly over GF(p) for the two primes 2^26-5 and 2^26-27 (balanced residues in
+ * double precision; the maximum is taken; it equals the rational rank unless a minor is divisible by both primes).
  * Replaces get_rank (utils.py:134-140: float SVD rank, summed). */
 int tg_rank_i32(const int8_t* state, int32_t* rank_out, int64_t B, int S,
                 int64_t game_stride_bytes, tg_stream_t stream);

@@ -13,12 +13,14 @@ resolved lazily.
 import importlib
 
 __version__ = "0.1.0"
-__all__ = ["TensorGameEnv", "SyntheticDemos", "TensorGameError", "functional", "ops", "demo_io", "shard_range"]
+__all__ = ["TensorGameEnv", "SyntheticDemos", "TranspositionTable", "TensorGameError", "functional", "ops", "demo_io",
+           "shard_range"]
 
-_SUBMODULES = {"_lib", "ops", "functional", "env", "generator", "sharding", "demo_io", "build"}
+_SUBMODULES = {"_lib", "ops", "functional", "env", "generator", "sharding", "demo_io", "build", "tree"}
 _ATTRS = {
     "TensorGameEnv": "env",
     "SyntheticDemos": "generator",
+    "TranspositionTable": "tree",
     "TensorGameError": "_lib",
     "shard_range": "sharding",
 }

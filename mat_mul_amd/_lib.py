@@ -40,6 +40,7 @@ SIGNATURES = {
     "tg_step_stream_i8": [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _p],
     "tg_step_stream_layout": [_i64, _i, _p, _p],
     "tg_expand_i8": [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i, _p],
+    "tg_expand_keyed_i8": [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i, _p],
     "tg_copy_i8": [_p, _p, _i64, _i, _i64, _i64, _p],
     "tg_done_i8": [_p, _p, _p, _i64, _i, _i64, _p],
     "tg_reset_matmul_i8": [_p, _i64, _i, _i64, _p],
@@ -50,6 +51,7 @@ SIGNATURES = {
     "tg_change_basis_i8": [_p, _p, _p, _p, _i64, _i, _i64, _p],
     "tg_emit_frames": [_p, _p, _p, _i, _i64, _i, _i, _i, C.c_float, _i64, _i64, _p],
     "tg_hash_u64": [_p, _p, _i64, _i, _i64, _p],
+    "tg_seen_u64": [_p, _p, _i64, _p, _p, _p, _i64, _i, _p],
     "tg_rank_i32": [_p, _p, _i64, _i, _i64, _p],
 }
 if AB_VARIANT:

@@ -186,15 +186,6 @@ __global__ __launch_bounds__(kBlock) void emit_frames_fast_kernel(const int8_t* 
 // N2: 64-bit state hash.  Team of lpg lanes per game (as done_kernel), 16 bytes = two words per
 // lane-iteration, wrapping sum across the team (order independent => any lane mapping is valid).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t fmix64(uint64_t k) {
-  k ^= k >> 33;
-  k *= 0xFF51AFD7ED558CCDull;
-  k ^= k >> 33;
-  k *= 0xC4CEB9FE1A85EC53ull;
-  k ^= k >> 33;
-  return k;
-}
-
 __global__ __launch_bounds__(kBlock) void hash_kernel(const int8_t* state, uint64_t* out, int64_t B, int N,
                                                       int64_t stride, int vec16, int lpg) {
   const int lt = threadIdx.x & (lpg - 1);
@@ -210,12 +201,7 @@ __global__ __launch_bounds__(kBlock) void hash_kernel(const int8_t* state, uint6
     int body_words = 0;
     if (vec16) {
       body_words = (N >> 4) << 1;  // whole 16-byte chunks
-      auto mix = [&](const uint4& q, int c) {
-        const uint64_t w0 = static_cast<uint64_t>(q.x) | (static_cast<uint64_t>(q.y) << 32);
-        const uint64_t w1 = static_cast<uint64_t>(q.z) | (static_cast<uint64_t>(q.w) << 32);
-        h += fmix64(w0 + static_cast<uint64_t>(2 * c + 1) * 0x9E3779B97F4A7C15ull);
-        h += fmix64(w1 + static_cast<uint64_t>(2 * c + 2) * 0x9E3779B97F4A7C15ull);
-      };
+      auto mix = [&](const uint4& q, int c) { h += hash_chunk(q, c); };
       const int nc = N >> 4;  // whole chunks
       int c = lt;
       for (; c + 3 * lpg < nc; c += 4 * lpg) {  // four chunks in flight per lane
@@ -237,7 +223,64 @@ __global__ __launch_bounds__(kBlock) void hash_kernel(const int8_t* state, uint6
       h += fmix64(w + static_cast<uint64_t>(k + 1) * 0x9E3779B97F4A7C15ull);
     }
     for (int off = lpg >> 1; off > 0; off >>= 1) h += __shfl_xor(h, off);
-    if (lt == 0 && live) out[g] = fmix64(h ^ (static_cast<uint64_t>(N) * 0xC2B2AE3D27D4EB4Full));
+    if (lt == 0 && live) out[g] = hash_finish(h, N);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// N2, second half: membership of 64-bit keys in the transposition table (act.py:188-195: `c not in new_mc_tree`;
+// act.py:209-211: the expanded state's key enters the tree).  The table is a caller-owned open-addressing array of
+// uint64 (capacity a power of two, 0 = empty slot; a key that IS 0 is stored as kSeenZeroKey), linear probing from
+// key & (capacity - 1) -- the keys are fmix64 outputs, already uniform.  Lookup and insertion are TWO kernels of one
+// call, so `fresh` is decided against the table as it was before the call (the reference filters all candidates of
+// an expansion first and records keys afterwards), independent of how lanes interleave.
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t kSeenZeroKey = 0x9E3779B97F4A7C15ull;
+
+__global__ __launch_bounds__(kBlock) void seen_lookup_kernel(const uint64_t* keys, const uint64_t* table, uint64_t capmask,
+                                                             uint8_t* fresh, const uint8_t* mask, int64_t n) {
+  const int64_t nthr = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += nthr) {
+    if (mask && !mask[i]) {
+      fresh[i] = 0;
+      continue;
+    }
+    uint64_t k = keys[i];
+    if (k == 0) k = kSeenZeroKey;
+    uint64_t slot = k & capmask;
+    bool found = false;
+    for (uint64_t probes = 0; probes <= capmask; ++probes) {  // a full table ends the walk after capacity probes
+      const uint64_t t = table[slot];
+      if (t == k) {
+        found = true;
+        break;
+      }
+      if (t == 0) break;
+      slot = (slot + 1) & capmask;
+    }
+    fresh[i] = found ? 0 : 1;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void seen_insert_kernel(const uint64_t* keys, uint64_t* table, uint64_t capmask,
+                                                             const uint8_t* mask, int64_t n, uint32_t* status) {
+  const int64_t nthr = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += nthr) {
+    if (mask && !mask[i]) continue;
+    uint64_t k = keys[i];
+    if (k == 0) k = kSeenZeroKey;
+    uint64_t slot = k & capmask;
+    bool placed = false;
+    for (uint64_t probes = 0; probes <= capmask; ++probes) {
+      const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(table + slot), 0ull,
+                                               static_cast<unsigned long long>(k));
+      if (old == 0ull || old == k) {  // claimed the empty slot, or the key is there already (possibly a sibling's)
+        placed = true;
+        break;
+      }
+      slot = (slot + 1) & capmask;
+    }
+    if (!placed && status) atomicOr(status, 1u);  // table full: the key was NOT recorded
   }
 }
 
@@ -414,6 +457,11 @@ int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_dtype,
   return launched(fn);
 }
 
+// the key pass of tg_expand_keyed_i8 for the kernel families that do not produce the keys themselves (tg_kernels.hip)
+int tg_internal_hash(const int8_t* state, uint64_t* hash_out, int64_t B, int S, int64_t stride, hipStream_t st) {
+  return tg_hash_u64(state, hash_out, B, S, stride, st);
+}
+
 int tg_hash_u64(const int8_t* state, uint64_t* hash_out, int64_t B, int S, int64_t game_stride_bytes,
                 tg_stream_t stream) {
   const char* fn = "tg_hash_u64";
@@ -431,6 +479,27 @@ int tg_hash_u64(const int8_t* state, uint64_t* hash_out, int64_t B, int S, int64
   (void)hipGetLastError();
   hipLaunchKernelGGL(tg::hash_kernel, dim3(grid_for(blocks, 8192)), dim3(tg::kBlock), 0,
                      static_cast<hipStream_t>(stream), state, hash_out, B, N, game_stride_bytes, vec16, lpg);
+  return launched(fn);
+}
+
+int tg_seen_u64(const uint64_t* keys, uint64_t* table, int64_t capacity, uint8_t* fresh, const uint8_t* mask,
+                uint32_t* status, int64_t n, int insert, tg_stream_t stream) {
+  const char* fn = "tg_seen_u64";
+  if (n < 0) return tg_internal_fail(TG_ERR_INVALID, "%s: n < 0", fn);
+  if (capacity < 2 || (capacity & (capacity - 1)) != 0)
+    return tg_internal_fail(TG_ERR_INVALID, "%s: capacity=%lld must be a power of two >= 2", fn, (long long)capacity);
+  if (!table) return tg_internal_fail(TG_ERR_INVALID, "%s: null table", fn);
+  if ((reinterpret_cast<uintptr_t>(table) & 7) || (reinterpret_cast<uintptr_t>(keys) & 7))
+    return tg_internal_fail(TG_ERR_INVALID, "%s: keys and table must be 8-byte aligned", fn);
+  if (n == 0) return TG_OK;
+  if (!keys || (!fresh && !insert)) return tg_internal_fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for((n + tg::kBlock - 1) / tg::kBlock, 8192)), block(tg::kBlock);
+  (void)hipGetLastError();
+  if (fresh)
+    hipLaunchKernelGGL(tg::seen_lookup_kernel, grid, block, 0, st, keys, table, static_cast<uint64_t>(capacity - 1), fresh, mask, n);
+  if (insert)
+    hipLaunchKernelGGL(tg::seen_insert_kernel, grid, block, 0, st, keys, table, static_cast<uint64_t>(capacity - 1), mask, n, status);
   return launched(fn);
 }
 

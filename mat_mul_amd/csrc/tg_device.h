@@ -80,6 +80,29 @@ __device__ __forceinline__ int count_nonzero_bytes(const uint4& q) {
   return count_nonzero_bytes(q.x) + count_nonzero_bytes(q.y) + count_nonzero_bytes(q.z) + count_nonzero_bytes(q.w);
 }
 
+// ---- the 64-bit state key (tg_hash_u64, include/tensor_game.h) -------------------------------
+// With the S^3 bytes zero-padded to 8-byte little-endian words w_k:
+//   H = fmix64( (sum_k fmix64(w_k + (k+1) * 0x9E3779B97F4A7C15)) ^ (S^3 * 0xC2B2AE3D27D4EB4F) ),
+// fmix64 = the MurmurHash3 finaliser.  The sum is order independent, so any mapping of chunks to lanes is valid.
+__device__ __forceinline__ uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xFF51AFD7ED558CCDull;
+  k ^= k >> 33;
+  k *= 0xC4CEB9FE1A85EC53ull;
+  k ^= k >> 33;
+  return k;
+}
+// the contribution of the 16-byte chunk c (words 2c and 2c+1) of a game
+__device__ __forceinline__ uint64_t hash_chunk(const uint4& q, int c) {
+  const uint64_t w0 = static_cast<uint64_t>(q.x) | (static_cast<uint64_t>(q.y) << 32);
+  const uint64_t w1 = static_cast<uint64_t>(q.z) | (static_cast<uint64_t>(q.w) << 32);
+  return fmix64(w0 + static_cast<uint64_t>(2 * c + 1) * 0x9E3779B97F4A7C15ull) +
+         fmix64(w1 + static_cast<uint64_t>(2 * c + 2) * 0x9E3779B97F4A7C15ull);
+}
+__device__ __forceinline__ uint64_t hash_finish(uint64_t sum, int N) {
+  return fmix64(sum ^ (static_cast<uint64_t>(N) * 0xC2B2AE3D27D4EB4Full));
+}
+
 // ---- team (sub-wave) reductions --------------------------------------------------------------
 
 // OR-reduce a predicate over the TS consecutive lanes (TS a power of two <= 64) this lane belongs to.

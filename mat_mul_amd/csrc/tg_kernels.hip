@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/tensor_game.h"
 #include "tg_device.h"
@@ -63,6 +64,7 @@ struct ApplyArgs {
   int shift;
   int only_flagged;      // MANY: redo only the games whose done_step is kNeedsExact (second pass after tg_mfma.h)
   int stream_out;        // EXPAND, S = 4 / 16: the children leave by non-temporal stores (output beyond kStreamOutBytes)
+  uint64_t* keys;        // EXPAND (B,nact), nullable: the 64-bit key of every child (tg_expand_keyed_i8)
 };
 
 // done_step value by which many_mfma_kernel hands a game to the lattice kernels (never a valid result)
@@ -739,7 +741,9 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
 // team-per-parent loop in s4_kernel<EXPAND> writes 64-byte pieces 64 k bytes apart).  The k teams of
 // a parent read the same 16-byte parent slices: one request per wavefront, served from L1/L2.  A
 // workgroup takes PB = 64 / k whole parents (k <= 64); lc / k by multiplication (recip = ceil(2^16 / k)).
-template <bool NT>
+// KEYS (tg_expand_keyed_i8): the 64-bit key of every child leaves with it -- the transposition-table filter of
+// extend_tree (act.py:188-195) then needs no second pass over the children.
+template <bool NT, bool KEYS = false>
 __global__ __launch_bounds__(kBlock) void s4_expand_kernel(ApplyArgs a, int PB, int recip) {
   const int k = a.nact;
   const int lg = threadIdx.x >> 2, q = threadIdx.x & 3;
@@ -763,6 +767,19 @@ __global__ __launch_bounds__(kBlock) void s4_expand_kernel(ApplyArgs a, int PB, 
   }
   const bool any_nz = team_any<4>(nz != 0);
   const bool any_ovf = team_any<4>((ovf & ~255) != 0);
+  if constexpr (KEYS) {
+    // the child's key while its four slices are in registers (tg_hash_u64's definition: slice q = chunk q); the team's
+    // sum by two quad-permute exchanges per half
+    uint64_t h = hash_chunk(o, q);
+    auto quad_xor = [](uint64_t v, auto ctrl) {
+      const uint32_t lo = __builtin_amdgcn_mov_dpp(static_cast<uint32_t>(v), decltype(ctrl)::value, 0xf, 0xf, true);
+      const uint32_t hi = __builtin_amdgcn_mov_dpp(static_cast<uint32_t>(v >> 32), decltype(ctrl)::value, 0xf, 0xf, true);
+      return static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
+    };
+    h += quad_xor(h, std::integral_constant<int, 0xB1>{});  // lanes (1,0,3,2)
+    h += quad_xor(h, std::integral_constant<int, 0x4E>{});  // lanes (2,3,0,1)
+    if (q == 0 && live) (a.keys + c0)[lc] = hash_finish(h, 64);
+  }
   if (q == 0 && live) {
     (a.done + c0)[lc] = any_nz ? 0 : 1;
     if (a.changed) {
@@ -1416,7 +1433,7 @@ unsigned capped_grid(int64_t blocks) {
 }
 
 template <int MODE>
-int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
+int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool* keys_fused = nullptr) {
   using namespace tg;
   ApplyArgs a = a_in;
   if (a.B == 0) return TG_OK;
@@ -1444,8 +1461,15 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
         const int64_t eblocks = (B + PB - 1) / PB;
         if (eblocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
         (void)hipGetLastError();
-        if (a.stream_out) hipLaunchKernelGGL(s4_expand_kernel<true>, dim3((unsigned)eblocks), dim3(kBlock), 0, st, a, PB, recip);
-        else hipLaunchKernelGGL(s4_expand_kernel<false>, dim3((unsigned)eblocks), dim3(kBlock), 0, st, a, PB, recip);
+        if (a.keys) {
+          if (a.stream_out) hipLaunchKernelGGL((s4_expand_kernel<true, true>), dim3((unsigned)eblocks), dim3(kBlock), 0, st, a, PB, recip);
+          else hipLaunchKernelGGL((s4_expand_kernel<false, true>), dim3((unsigned)eblocks), dim3(kBlock), 0, st, a, PB, recip);
+          if (keys_fused) *keys_fused = true;
+        } else if (a.stream_out) {
+          hipLaunchKernelGGL((s4_expand_kernel<true>), dim3((unsigned)eblocks), dim3(kBlock), 0, st, a, PB, recip);
+        } else {
+          hipLaunchKernelGGL((s4_expand_kernel<false>), dim3((unsigned)eblocks), dim3(kBlock), 0, st, a, PB, recip);
+        }
         return check_launch(fn);
       }
     }
@@ -1591,9 +1615,9 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
       (void)hipGetLastError();
       // whole-line stores pay from ~100 MiB of states on (measured: 6.0 / 7.0 us at 32 MiB, 26.3 / 25.5 at 128 MiB,
       // 50.3 / 47.0 at 256 MiB, 150 / 128 at 512 MiB, 16-byte stores / whole lines)
-      if (B * a.in_stride >= (320ll << 20) || TG_SWITCH("TG_S16_NT_LOADS"))  // beyond the Infinity Cache (A/B switch: tests)
+      if ((B * a.in_stride >= (320ll << 20) || TG_SWITCH("TG_S16_NT_LOADS")) && !TG_SWITCH("TG_S16_NO_NT_LOADS"))  // beyond the Infinity Cache (A/B switch: tests)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
-      else if (B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES"))  // (A/B switch: tests at small batches)
+      else if ((B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES")) && !TG_SWITCH("TG_S16_NO_LINES"))  // (A/B switch: tests at small batches)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
       else
         hipLaunchKernelGGL((s16_step_kernel<MODE, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
@@ -1626,9 +1650,9 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st) {
       (void)hipGetLastError();
       // as at S=16: whole-line stores once the batch leaves the caches, non-temporal state loads beyond the Infinity
       // Cache (A/B switches: the variants at test sizes)
-      if (B * a.in_stride >= (320ll << 20) || TG_SWITCH("TG_S25_NT_LOADS"))
+      if ((B * a.in_stride >= (320ll << 20) || TG_SWITCH("TG_S25_NT_LOADS")) && !TG_SWITCH("TG_S25_NO_NT_LOADS"))
         hipLaunchKernelGGL((s25_step_kernel<true, true>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
-      else if (B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S25_LINES"))
+      else if ((B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S25_LINES")) && !TG_SWITCH("TG_S25_NO_LINES"))
         hipLaunchKernelGGL((s25_step_kernel<true, false>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
       else
         hipLaunchKernelGGL((s25_step_kernel<false, false>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
@@ -1856,19 +1880,41 @@ int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* act
   return launch_apply<tg::MANY>("tg_step_many_i8", a, static_cast<hipStream_t>(stream));
 }
 
+int tg_internal_hash(const int8_t* state, uint64_t* hash_out, int64_t B, int S, int64_t stride, hipStream_t st);  // tg_aux.hip
+
+static int expand_common(const char* fn, const int8_t* state_in, int8_t* state_out, const int8_t* actions, uint8_t* done,
+                         uint8_t* changed, uint8_t* overflow, uint64_t* keys_out, int64_t B, int S, int k,
+                         int64_t in_stride_bytes, int64_t out_stride_bytes, int shift, tg_stream_t stream) {
+  if (int rc = validate_common(fn, B, S, in_stride_bytes)) return rc;
+  if (int rc = validate_common(fn, B, S, out_stride_bytes)) return rc;
+  if (k < 1 || k > TG_MAX_ACTIONS) return fail(TG_ERR_INVALID, "%s: k=%d outside [1,%d]", fn, k, TG_MAX_ACTIONS);
+  if (B && (!state_in || !state_out || !actions || !done)) return fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  if (B && state_in == state_out) return fail(TG_ERR_INVALID, "%s: in-place expansion is not defined", fn);
+  if (reinterpret_cast<uintptr_t>(keys_out) & 7) return fail(TG_ERR_INVALID, "%s: keys_out must be 8-byte aligned", fn);
+  tg::ApplyArgs a{state_in, state_out, actions, done, nullptr, changed, overflow, B,
+                  in_stride_bytes, out_stride_bytes, S, k, shift};
+  a.keys = keys_out;
+  bool fused = false;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = launch_apply<tg::EXPAND>(fn, a, st, &fused)) return rc;
+  // kernel families that do not hash the children while they hold them: one pass of the key kernel over the children
+  // just written (S = 4, the shape MCTS expansion runs at in the reference, is fused)
+  if (keys_out && B && !fused) return tg_internal_hash(state_out, keys_out, B * k, S, out_stride_bytes, st);
+  return TG_OK;
+}
+
 int tg_expand_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions, uint8_t* done,
                  uint8_t* changed, uint8_t* overflow, int64_t B, int S, int k,
                  int64_t in_stride_bytes, int64_t out_stride_bytes, int shift, tg_stream_t stream) {
-  if (int rc = validate_common("tg_expand_i8", B, S, in_stride_bytes)) return rc;
-  if (int rc = validate_common("tg_expand_i8", B, S, out_stride_bytes)) return rc;
-  if (k < 1 || k > TG_MAX_ACTIONS)
-    return fail(TG_ERR_INVALID, "tg_expand_i8: k=%d outside [1,%d]", k, TG_MAX_ACTIONS);
-  if (B && (!state_in || !state_out || !actions || !done))
-    return fail(TG_ERR_INVALID, "tg_expand_i8: null pointer");
-  if (B && state_in == state_out) return fail(TG_ERR_INVALID, "tg_expand_i8: in-place expansion is not defined");
-  tg::ApplyArgs a{state_in, state_out, actions, done, nullptr, changed, overflow, B,
-                  in_stride_bytes, out_stride_bytes, S, k, shift};
-  return launch_apply<tg::EXPAND>("tg_expand_i8", a, static_cast<hipStream_t>(stream));
+  return expand_common("tg_expand_i8", state_in, state_out, actions, done, changed, overflow, nullptr, B, S, k,
+                       in_stride_bytes, out_stride_bytes, shift, stream);
+}
+
+int tg_expand_keyed_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions, uint8_t* done,
+                       uint8_t* changed, uint8_t* overflow, uint64_t* keys_out, int64_t B, int S, int k,
+                       int64_t in_stride_bytes, int64_t out_stride_bytes, int shift, tg_stream_t stream) {
+  return expand_common("tg_expand_keyed_i8", state_in, state_out, actions, done, changed, overflow, keys_out, B, S, k,
+                       in_stride_bytes, out_stride_bytes, shift, stream);
 }
 
 int tg_gen_from_factors_i8(const int8_t* actions, int8_t* target_out, uint8_t* overflow, int64_t B,
@@ -1903,7 +1949,10 @@ int tg_copy_i8(const int8_t* state_in, int8_t* state_out, int64_t B, int S, int6
     // nt loads / nt loads + stores): 256 MiB 33 / 34 / 41 us, 384 MiB 67 / 49 / 61, 512 MiB 88 / 71 / 81, 768 MiB
     // 131 / 127 / 120, 1 GiB 172 / 167 / 160.  This kernel is the bench's copy ceiling: it has to be the best copy.
     const int64_t both = state_in == state_out ? 0 : B * (in_stride_bytes + out_stride_bytes);
-    if (both > (640ll << 20) || TG_SWITCH("TG_COPY_NT2"))
+    if (TG_SWITCH("TG_COPY_PLAIN"))
+      hipLaunchKernelGGL(tg::copy_kernel<0>, dim3((unsigned)blocks), dim3(tg::kBlock), 0, st, state_in, state_out, B, nchunk,
+                         sh, N % 16, in_stride_bytes, out_stride_bytes);
+    else if (both > (640ll << 20) || TG_SWITCH("TG_COPY_NT2"))
       hipLaunchKernelGGL(tg::copy_kernel<2>, dim3((unsigned)blocks), dim3(tg::kBlock), 0, st, state_in, state_out, B, nchunk,
                          sh, N % 16, in_stride_bytes, out_stride_bytes);
     else if (both > (256ll << 20) || TG_SWITCH("TG_COPY_NT1"))

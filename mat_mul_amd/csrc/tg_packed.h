@@ -624,9 +624,10 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
 //
 // LINES / NTL (batches that stream from HBM, as s16_step_kernel's): the dense pass hands its results back through the
 // queue and every lane stores its own chunks at 128-byte-LINE granularity -- a chunk is stored when any chunk of its
-// line changed (a game starts 16 g bytes into a line, so the eight chunks of a line are eight consecutive lanes from
-// lane (-(g + 250 n)) mod 8 on; lines that straddle two wavefronts or two games stay partial) -- and, beyond the
-// Infinity Cache, the state is read by non-temporal loads.
+// line changed (a game starts o = (address / 16) mod 8 chunks into a line -- o = g mod 8 on the 15 632-byte stride, 0 on a
+// 128-byte-multiple stride -- so the eight chunks of a line are eight consecutive lanes from lane (-(o + 250 n)) mod 8 on;
+// lines that straddle two wavefronts or two games stay partial) -- and, beyond the Infinity Cache, the state is read by
+// non-temporal loads.
 template <bool LINES, bool NTL>
 __global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyArgs a) {  // (6 spills at 64 VGPRs)
   constexpr int S = 25;
@@ -798,7 +799,7 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyAr
         if (inplace) {
           // the lanes of my line: (g + c) >> 3 equal, i.e. eight consecutive lanes from a multiple of 8 minus sh on
           const unsigned long long m = __ballot(chg);
-          const int sh = static_cast<int>((g + G::TSA * n) & 7);
+          const int sh = static_cast<int>(((reinterpret_cast<uintptr_t>(out) >> 4) + G::TSA * n) & 7);  // any 16-byte-multiple stride
           const int first = ((lane + sh) & ~7) - sh;  // may be negative: the line began in the previous wavefront
           const int lo = max(first, 0), hi = min(first + 8, 64);
           st = ((m >> lo) & ((1ull << (hi - lo)) - 1ull)) != 0;

@@ -19,7 +19,7 @@ from ._lib import TG_MAX_ACTIONS, TG_MAX_S, TG_MAX_VALUES, TensorGameError, call
 __all__ = [
     "step", "step_sparse", "copy_states", "prepare_step", "step_many", "step_stream", "step_stream_layout", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
     "gen_demos", "sample_basis", "change_basis", "as_tokens", "categorical_thresholds",
-    "alloc_states", "alloc_ring", "emit_frames", "state_hash", "slice_rank",
+    "alloc_states", "alloc_ring", "emit_frames", "state_hash", "slice_rank", "alloc_seen_table", "seen",
 ]
 
 
@@ -240,10 +240,13 @@ def step_stream(state, actions, done=None, overflow=None, ready=None, progress=N
     return state, done
 
 
-def expand(state, actions, out=None, done=None, changed=None, overflow=None, shift: int = 1):
+def expand(state, actions, out=None, done=None, changed=None, overflow=None, shift: int = 1, want_keys: bool = False,
+           keys=None):
     """k children per parent.  actions int8 (B,k,3S) -> children int8 (B,k,S,S,S), done (B,k),
     changed (B,k).  == reference get_child_states (act.py:266-275) with k>1, T=1, plus the
-    per-game form of remove_null_actions (utils.py:191-194)."""
+    per-game form of remove_null_actions (utils.py:191-194).  ``want_keys`` (or a ``keys`` int64 (B,k) tensor) also
+    returns the 64-bit key of every child (== ``state_hash`` of the child; the state_to_str keys of act.py:188-190):
+    (children, done, changed, keys)."""
     B, S, stride = _state_layout(state, "state")
     dev = state.device
     if actions.dim() != 3:
@@ -270,6 +273,14 @@ def expand(state, actions, out=None, done=None, changed=None, overflow=None, shi
     done = _flag(done, (B, k), torch.uint8, dev, "done")
     changed = _flag(changed, (B, k), torch.uint8, dev, "changed")
     overflow = _flag(overflow, (B, k), torch.uint8, dev, "overflow")
+    if want_keys and keys is None:
+        keys = torch.empty((B, k), dtype=torch.int64, device=dev)
+    if keys is not None:
+        keys = _flag(keys, (B, k), torch.int64, dev, "keys")
+        with torch.cuda.device(dev):
+            call("tg_expand_keyed_i8", _ptr(state), _ptr(out), _ptr(actions), _ptr(done), _ptr(changed),
+                 _ptr(overflow), _ptr(keys), B, S, k, stride, ostride, int(shift), _stream(dev))
+        return out, done, changed, keys
     with torch.cuda.device(dev):
         call("tg_expand_i8", _ptr(state), _ptr(out), _ptr(actions), _ptr(done), _ptr(changed),
              _ptr(overflow), B, S, k, stride, ostride, int(shift), _stream(dev))
@@ -469,6 +480,41 @@ def state_hash(state) -> torch.Tensor:
     with torch.cuda.device(state.device):
         call("tg_hash_u64", _ptr(state), _ptr(out), B, S, stride, _stream(state.device))
     return out
+
+
+def alloc_seen_table(capacity: int, device) -> torch.Tensor:
+    """An empty transposition table for ``seen``: int64 (capacity,) zeros, capacity a power of two (keep it at most
+    half full)."""
+    if capacity < 2 or capacity & (capacity - 1):
+        raise TensorGameError("alloc_seen_table", -1, "capacity must be a power of two >= 2")
+    return torch.zeros((capacity,), dtype=torch.int64, device=device)
+
+
+def seen(keys, table, mask=None, insert: bool = False, status=None, fresh=None) -> torch.Tensor:
+    """fresh[i] = mask[i] and keys[i] not in table (as it was BEFORE the call); with ``insert`` every masked key is in
+    the table afterwards.  == the tree filter of extend_tree (act.py:188-195: ``c not in new_mc_tree``) and the
+    recording of the expanded state's key (act.py:209-211), on the 64-bit keys of ``state_hash``.  ``keys`` may have any
+    shape (int64 bits of the uint64 keys); ``mask`` uint8 of the same shape (e.g. ``changed`` of ``expand``);
+    ``status`` int32 (1,): bit 0 set when the table was full.  Returns fresh (uint8, shape of keys)."""
+    _need_gpu(keys, "keys")
+    _need_gpu(table, "table")
+    dev = keys.device
+    if keys.dtype != torch.int64 or not keys.is_contiguous():
+        raise TensorGameError("seen", -1, "keys must be contiguous int64 (the bits of the uint64 keys)")
+    if table.dtype != torch.int64 or table.dim() != 1 or not table.is_contiguous() or table.device != dev:
+        raise TensorGameError("seen", -1, f"table must be a contiguous int64 vector on {dev} (ops.alloc_seen_table)")
+    n = keys.numel()
+    if mask is not None:
+        mask = _flag(mask, tuple(keys.shape), torch.uint8, dev, "mask")
+    if fresh is None:
+        fresh = torch.empty(tuple(keys.shape), dtype=torch.uint8, device=dev)
+    fresh = _flag(fresh, tuple(keys.shape), torch.uint8, dev, "fresh")
+    if status is not None and (status.dtype not in (torch.int32, torch.uint32) or status.numel() != 1 or status.device != dev):
+        raise TensorGameError("seen", -1, f"status must be one 32-bit word on {dev}")
+    with torch.cuda.device(dev):
+        call("tg_seen_u64", _ptr(keys), _ptr(table), table.numel(), _ptr(fresh), _ptr(mask), _ptr(status), n,
+             1 if insert else 0, _stream(dev))
+    return fresh
 
 
 def slice_rank(state) -> torch.Tensor:

@@ -439,6 +439,33 @@ def state_hash(state) -> np.ndarray:
         return _fmix64(h ^ (np.uint64(N) * np.uint64(0xC2B2AE3D27D4EB4F)))
 
 
+def seen_u64(keys, table: set, mask=None, insert=False) -> np.ndarray:
+    """N2, second half (include/tensor_game.h::tg_seen_u64): fresh[i] = mask[i] and keys[i] not in `table`, decided
+    against the table as it was BEFORE the call; with `insert` every masked key is in the table afterwards.  `table`
+    is a Python set of ints -- exactly the role of `new_mc_tree`'s keys in extend_tree (act.py:188-195: `c not in
+    new_mc_tree`; act.py:209-211: the expanded state enters the tree), on 64-bit keys instead of state_to_str strings."""
+    k = np.asarray(keys, np.uint64)
+    m = np.ones(k.shape, bool) if mask is None else np.asarray(mask).astype(bool)
+    flat = [int(x) for x in k.reshape(-1)]
+    fresh = np.array([mm and (x not in table) for x, mm in zip(flat, m.reshape(-1))], np.uint8).reshape(k.shape)
+    if insert:
+        table.update(x for x, mm in zip(flat, m.reshape(-1)) if mm)
+    return fresh
+
+
+def tree_filter(parent, actions, table: set, shift=1):
+    """The candidate filter of extend_tree (act.py:183-195) for ONE expanded state: children = parent - tensor(action)
+    (get_child_states, act.py:266-275), drop the children equal to the parent (remove_null_actions, utils.py:191-194),
+    drop those whose key is already a key of the tree.  parent int8 (S,S,S), actions (k,3S) tokens.
+    Returns (kept uint8 (k,), child keys uint64 (k,), changed uint8 (k,))."""
+    parent = np.asarray(parent).astype(np.int64)
+    actions = np.asarray(actions)
+    kids = parent[None] - action_to_tensor(actions, shift)
+    changed = (kids != parent[None]).reshape(len(actions), -1).any(axis=1).astype(np.uint8)
+    keys = state_hash(kids.astype(np.int8))
+    return seen_u64(keys, table, mask=changed), keys, changed
+
+
 def _rank_bareiss(m):
     """Exact rational rank of an integer matrix (list of lists of Python ints): Bareiss
     fraction-free elimination -- every division is exact, entries stay minors of the input."""

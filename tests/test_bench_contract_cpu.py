@@ -30,19 +30,35 @@ def test_algorithmic_bytes_per_step(bench):
 def test_roofline_object(bench):
     # 9 samples of 1000 launches around 2.5 ms -> 2.5 us per launch (median)
     r = bench.roofline(65536, 4, 1000, [2.5] * 5 + [2.4, 2.6, 9.0, 2.5], None, (4200.0, 2.2))
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["bound"] == "launch" and r["unit"] == "GB/s" and r["peak"] == 8000.0   # 4 MiB of states: L2-resident
     assert r["bytes_per_launch"] == r["needed_bytes_per_launch"] == 65536 * 141
     assert abs(r["avg_launch_us"] - 2.5) < 1e-9 and len(r["launch_us_samples"]) == 9
     assert abs(r["achieved"] - 65536 * 141 / 2.5e-6 / 1e9) < 0.01
     assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4 and r["frac"] == r["frac_algorithmic"]
     assert r["copy_ceiling_GBps"] == 4200.0 and abs(r["frac_of_copy_ceiling"] - r["achieved"] / 4200.0) < 1e-3
-    assert r["regime"].startswith("cache-resident")
+    assert r["regime"].startswith("L2-resident") and "hbm_copy_ceiling_GBps" not in r
     # traffic comes from the committed PMC summary of the newest round that recorded this kernel
     if r["traffic"] is not None:
         t = json.loads((ROOT / "profiles" / f"traffic_{r['traffic_round']}.json").read_text())
         assert r["traffic"] == t["S4_B65536"]["hbm_bytes_per_launch"]
         assert 0.95 < r["traffic"] / r["bytes_per_launch"] < 1.05  # S=4 moves what the algorithm needs, no more
         assert abs(r["frac_traffic"] - r["traffic"] / 2.5e-6 / 1e9 / 8000.0) < 1e-3
+
+
+def test_regimes_by_footprint(bench):
+    """Only footprints of 2 GiB and more are labelled (and bounded) as HBM streams; everything the caches can hold or
+    assist says so (256-512 MiB 'HBM' lines moved more bytes per second than HBM delivers)."""
+    labels = [(bench.regime_of(n)[1], bench.regime_of(n)[0].split(":")[0]) for n in
+              (4 << 20, 31 << 20, 32 << 20, 255 << 20, 256 << 20, 512 << 20, (2 << 30) - 1, 2 << 30, 4 << 30)]
+    assert labels == [("launch", "L2-resident"), ("launch", "L2-resident"), ("cache", "Infinity-Cache-resident"),
+                      ("cache", "Infinity-Cache-resident"), ("cache", "cache-assisted"), ("cache", "cache-assisted"),
+                      ("cache", "cache-assisted"), ("hbm", "hbm-streaming"), ("hbm", "hbm-streaming")]
+    # an HBM line carries the copy ceiling measured in the run and its fraction of it
+    r = bench.roofline(1 << 25, 4, 16, [0.82 * 16] * 3, None, (6700.0, 640.0), hbm_copy=(6700.0, 640.0))
+    assert r["bound"] == "hbm" and r["hbm_copy_ceiling_GBps"] == 6700.0 and r["hbm_achievable_GBps_guide"] == 6300.0
+    assert abs(r["frac_of_hbm_copy_ceiling"] - r["achieved"] / 6700.0) < 1e-3 and r["frac"] < r["frac_of_hbm_copy_ceiling"]
+    r = bench.roofline(8192, 16, 512, [6.0e-3 * 512] * 3, None, None, hbm_copy=(6700.0, 640.0))
+    assert r["bound"] == "cache" and "frac_of_hbm_copy_ceiling" not in r
 
 
 def test_no_fraction_above_one_from_skipped_stores(bench):

@@ -3,6 +3,7 @@
 The fixtures under tests/golden/ were produced by RUNNING the reference
 (tests/golden/make_golden.py).  Everything here is CPU-only."""
 import hashlib
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -205,3 +206,55 @@ def test_notebook_known_answers(golden):
     first = O.uvw_to_tensor((g["uu"][0], g["vv"][0], g["ww"][0]))                                          # cell 14 printout
     assert {tuple(ix) for ix in np.argwhere(first == 1)} == {(0, 0, 0), (0, 0, 3), (0, 3, 0), (0, 3, 3),
                                                              (3, 0, 0), (3, 0, 3), (3, 3, 0), (3, 3, 3)}
+
+
+# ---------------------------------------------------------------------------------------------
+# N2, second half: the tree filter of extend_tree (act.py:183-195, 209-211), recorded from the reference
+# ---------------------------------------------------------------------------------------------
+TREE_CASES = ["S4_T1", "S4_T2", "S9_T1", "S4_rand", "S4_transp", "S9_transp"]
+
+
+def replay_tree_fixture(name, filter_fn, commit_fn):
+    """Walks the recorded expansion attempts in order.  filter_fn(parent, actions) -> kept mask (k,);
+    commit_fn(parent) records the expanded state.  Asserts the survivors are the reference's, in order."""
+    g = np.load(Path(__file__).resolve().parent / "golden" / "tree_filter.npz")
+    parents, actions, n_kept, kept, commit = (g[f"{name}_{f}"] for f in ("parent", "actions", "n_kept", "kept", "commit"))
+    dropped_by_tree = 0
+    for e in range(len(parents)):
+        mask, changed = filter_fn(parents[e], actions[e])
+        mask = np.asarray(mask).astype(bool)
+        assert int(mask.sum()) == int(n_kept[e]), (name, e)
+        assert np.array_equal(actions[e][mask], kept[e][: n_kept[e]]), (name, e)
+        dropped_by_tree += int((np.asarray(changed).astype(bool) & ~mask).sum())
+        if commit[e]:
+            assert n_kept[e] >= 1
+            commit_fn(parents[e])
+        else:
+            assert n_kept[e] == 0      # the reference asked the network again
+    return dropped_by_tree
+
+
+@pytest.mark.parametrize("name", TREE_CASES)
+def test_tree_filter_matches_reference_extend_tree(name):
+    table = set()
+
+    def filt(parent, acts):
+        kept, _, changed = O.tree_filter(parent, acts, table)
+        return kept, changed
+
+    def commit(parent):
+        O.seen_u64(O.state_hash(parent[None]), table, insert=True)
+
+    dropped = replay_tree_fixture(name, filt, commit)
+    if name.endswith("transp"):
+        assert dropped >= 20, "the transposition cases must exercise the membership test, not only null actions"
+
+
+def test_seen_semantics():
+    t = set()
+    k = np.array([5, 7, 5, 0, 9], np.uint64)
+    assert O.seen_u64(k, t, insert=True).tolist() == [1, 1, 1, 1, 1]     # equal keys of one call are all fresh
+    assert t == {5, 7, 0, 9}
+    assert O.seen_u64(k, t, mask=np.array([1, 0, 1, 1, 1])).tolist() == [0, 0, 0, 0, 0]
+    assert O.seen_u64(np.array([11, 5], np.uint64), t, mask=np.array([0, 1]), insert=True).tolist() == [0, 0]
+    assert 11 not in t                                                    # masked-out keys are not recorded
