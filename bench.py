@@ -74,17 +74,22 @@ STEP_KERNEL = {9: "tg::s9_step_kernel<0>"}
 
 
 def step_kernel_name(S: int, B: int) -> str:
-    """The kernel tg_step_i8 launches for aligned int8 states (tg_kernels.hip, apply_launch)."""
-    if S == 4:  # non-temporal state loads from 96 MiB of states on
-        return "tg::s4_kernel<0, true>" if B * 64 >= (96 << 20) else "tg::s4_kernel<0, false>"
-    if S == 16:  # whole-line stores from 96 MiB of states on, non-temporal state loads from 320 MiB on
-        if B * 4096 >= (320 << 20):
+    """The kernel tg_step_i8 launches for aligned int8 states (tg_kernels.hip, launch_apply)."""
+    MiB = 1 << 20
+    if S == 4:  # non-temporal state loads from 96 MiB of states on, token wait from 384 MiB on
+        b = B * 64
+        return "tg::s4_step_kernel<true, true>" if b >= 384 * MiB else (
+            "tg::s4_step_kernel<true, false>" if b >= 96 * MiB else "tg::s4_step_kernel<false, false>")
+    if S == 16:  # whole-line stores from 96 MiB of states on, non-temporal state loads in [320 MiB, 1.25 GiB)
+        b = B * 4096
+        if 320 * MiB <= b < 1280 * MiB:
             return "tg::s16_step_kernel<0, true, true>"
-        return "tg::s16_step_kernel<0, true, false>" if B * 4096 >= (96 << 20) else "tg::s16_step_kernel<0, false, false>"
-    if S == 25:  # the same two thresholds on 15 632-byte game strides
-        if B * 15632 >= (320 << 20):
+        return "tg::s16_step_kernel<0, true, false>" if b >= 96 * MiB else "tg::s16_step_kernel<0, false, false>"
+    if S == 25:  # 15 632-byte game strides: lines in [96 MiB, 1.25 GiB), nt loads in [320 MiB, 1.25 GiB), plain beyond
+        b = B * 15632
+        if 320 * MiB <= b < 1280 * MiB:
             return "tg::s25_step_kernel<true, true>"
-        return "tg::s25_step_kernel<true, false>" if B * 15632 >= (96 << 20) else "tg::s25_step_kernel<false, false>"
+        return "tg::s25_step_kernel<true, false>" if 96 * MiB <= b < 1280 * MiB else "tg::s25_step_kernel<false, false>"
     return STEP_KERNEL.get(S, "tg::slow_kernel<0>")
 
 
@@ -650,7 +655,7 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
             (25, 1 << 15, 64, "BASELINE config 5 whole on ONE GPU (488 MiB of states, cache-assisted)", "demo"),
             (4, 1 << 25, 16, "HBM stream: 2 GiB of states", "demo"),
             (16, 1 << 19, 16, "HBM stream: 2 GiB of states", "demo"),
-            (25, 1 << 17, 16, "HBM stream: 1.9 GiB of states", "demo")]:
+            (25, 139264, 16, "HBM stream: 2.0 GiB of states", "demo")]:
         if kind == "demo" and s2 == S_main and b2 == B_main:
             continue
         if kind == "demo":
@@ -751,6 +756,17 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
                      "GBps": round(nbytes / sec / 1e9, 1), "hbm_frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
                      "TMACps": round(b2 * r2 * s2 ** 3 / sec / 1e12, 2),
                      "int8_mfma_frac": round(2 * b2 * r2 * s2 ** 3 / sec / 5.0e15, 4)})
+        # which bound binds: neither HBM (hbm_frac) nor the matrix cores (int8_mfma_frac) -- the vector ALU's
+        # instruction issue: Philox, draw evaluation, the byte products and the packing around the MFMAs
+        insts, rnd = generator_valu_instructions(with_basis)
+        also[-1]["bound"] = "valu"
+        if insts:
+            also[-1]["valu_issue_frac"] = round(insts * VALU_ISSUE_CYCLES / (SIMDS * SHADER_CLOCK_HZ * sec), 4)
+            also[-1]["valu_instructions_per_launch"] = int(insts)
+            also[-1]["valu_counter_round"] = rnd
+            also[-1]["valu_note"] = ("SQ_INSTS_VALU of the committed PMC pass x 4 issue cycles / (1024 SIMDs x 2.4 GHz x the time "
+                                     "measured here); issue alone (measured 4.3 cycles per VOP3 instruction, "
+                                     "profiles/r02_issue_rates.txt) would read %.2f" % (insts * 4.3 / (SIMDS * SHADER_CLOCK_HZ * sec)))
     # get_child_states with k > 1 (act.py:266-275, the shape MCTS expansion calls): k children per parent in one launch;
     # bytes = parent read + k x (child written + tokens read + done + changed)
     for s2, b2 in ((4, 65536), (4, 1 << 20), (9, 32768), (16, 8192), (25, 4096)):
@@ -768,7 +784,75 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
                      "ok": ok, "value": round(b2 * k2 / sec, 1), "unit": "children/s", "us_per_launch": round(sec * 1e6, 2),
                      "GBps": round(nbytes / sec / 1e9, 1), "hbm_frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4)})
         del kids, kd, kc, tok, tgt
+    also += fused_lines(dev)
     return also
+
+
+def fused_lines(dev, batches=(65536, 1 << 20)):
+    """SURVEY N1 / N2 fused entries against the two calls they replace (S=4: the shape MCTS expansion runs at)."""
+    from mat_mul_amd import ops
+
+    also = []
+    for b2 in batches:
+        s2, T, k2 = 4, 4, 8
+        reps = 20 if b2 <= 65536 else 5
+        tok, tgt = ops.gen_demos(b2, s2, k2, dev, seed=6)
+        a0 = tok[:, 0].contiguous()
+        ring = ops.alloc_ring(b2, s2, T, dev)
+        for f in range(T):
+            ring[:, f].copy_(tgt)
+        dn = torch.zeros(b2, dtype=torch.uint8, device=dev)
+        sc = torch.empty((b2, 1), dtype=torch.float32, device=dev)
+        for dt, w in ((torch.float16, 2), (torch.float32, 4)):
+            x = torch.empty((b2, T, s2, s2, s2), dtype=dt, device=dev)
+            fused = graph_time(lambda: ops.step_emit(ring, 0, a0, 1.0, dt, out=x, scalars=sc, done=dn), dev, reps=reps)
+            xf = x.clone()
+            two = graph_time(lambda: (ops.step(ring[:, 0], a0, out=ring[:, 1], done=dn),
+                                      ops.emit_frames(ring, 1, 1.0, dt, out=x, scalars=sc)), dev, reps=reps)
+            nbytes = b2 * (s2 ** 3 * (T - 1) + 3 * s2 + s2 ** 3 + 1 + T * s2 ** 3 * w + 4)
+            also.append({"workload": f"N1 FUSED tg_step_emit: S={s2} batch={b2} T={T} {str(dt)[6:]}: one step on the history "
+                                     f"ring + the (B,T,S,S,S) model input of the new state in one launch",
+                         "ok": bool(torch.equal(x, xf)), "us_per_launch": round(fused * 1e6, 2),
+                         "us_step_then_emit_frames": round(two * 1e6, 2), "gain": round(two / fused, 3),
+                         "GBps": round(nbytes / fused / 1e9, 1), "hbm_frac": round(nbytes / fused / 1e9 / HBM_PEAK_GBS, 4)})
+            del x, xf
+        kids = ops.alloc_states(b2 * k2, s2, dev).unflatten(0, (b2, k2))
+        kd = torch.zeros((b2, k2), dtype=torch.uint8, device=dev)
+        kc = torch.zeros((b2, k2), dtype=torch.uint8, device=dev)
+        keys = torch.zeros((b2, k2), dtype=torch.int64, device=dev)
+        table = ops.alloc_seen_table(1 << 25, dev)
+        fresh = torch.zeros((b2, k2), dtype=torch.uint8, device=dev)
+        fused = graph_time(lambda: ops.expand(tgt, tok, out=kids, done=kd, changed=kc, keys=keys), dev, reps=reps)
+        kf = keys.clone()
+        two = graph_time(lambda: (ops.expand(tgt, tok, out=kids, done=kd, changed=kc),
+                                  keys.view(-1).copy_(ops.state_hash(kids.flatten(0, 1)))), dev, reps=reps)
+        look = graph_time(lambda: ops.seen(keys, table, mask=kc, fresh=fresh), dev, reps=reps)
+        also.append({"workload": f"N2 FUSED tg_expand_keyed_i8: S={s2} batch={b2}, k={k2}: children + their 64-bit keys in one "
+                                 f"launch (extend_tree's state_to_str per child, act.py:188-190), then tg_seen_u64 on the keys",
+                     "ok": bool(torch.equal(keys, kf)), "us_per_launch": round(fused * 1e6, 2),
+                     "us_expand_then_hash": round(two * 1e6, 2), "gain": round(two / fused, 3),
+                     "us_seen_lookup": round(look * 1e6, 2), "keys_per_s_lookup": round(b2 * k2 / look, 1)})
+        del kids, kd, kc, keys, table, fresh, ring
+    return also
+
+
+SIMDS, SHADER_CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 4  # MI355X: 256 CUs x 4 SIMDs; s_memtime clock; a wave64 VALU op holds a SIMD 4 cycles
+
+
+def generator_valu_instructions(with_basis):
+    """SQ_INSTS_VALU per launch of the fused generator at BASELINE config 5's per-GPU share (S=25, R=64, 4 096 demos)
+    from the newest committed rocprofv3 --pmc pass (profiles/rNN_mfma_pmc.json): the instruction count of a launch
+    does not depend on the clock, so it can be priced against the time measured live."""
+    want = "tg::gen_fused_kernel<25, 2, %s," % ("true" if with_basis else "false")
+    for f in sorted((ROOT / "profiles").glob("r*_mfma_pmc.json"), reverse=True):
+        try:
+            d = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        for k, e in d.items():
+            if k.startswith(want) and "SQ_INSTS_VALU" in e:
+                return e["SQ_INSTS_VALU"], f.stem.split("_")[0]
+    return None, None
 
 
 def graph_time(fn, dev, reps, samples=5):

@@ -71,20 +71,6 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
                uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes, int shift,
                tg_stream_t stream);
 
-#ifdef TG_AB_SWITCHES
-/* A/B BUILD ONLY (libtensorgame_ab.so, -DTG_AB_SWITCHES; not part of the product library): measured slower
- * than tg_step_i8 on MI355X and kept as a measurement reference.
- * The same step, IN PLACE, for a caller that carries the number of non-zero entries of every game:
- * nnz (int32 (B), in/out) must hold the exact count on entry and holds it on return (the rank bound
- * of training.py:266, free of charge); done[b] = (nnz[b] == 0).  With the count at hand a kernel need
- * not read the whole state: chunks that the action does not touch are neither loaded nor stored.
- * Same results as tg_step_i8.  Measured note: this moves far fewer bytes but is NOT faster than
- * tg_step_i8 on MI355X, so use it for the carried count, not for speed. */
-int tg_step_sparse_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_t* done,
-                      uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes, int shift,
-                      tg_stream_t stream);
-#endif
-
 /* K sequential steps with the state resident on chip.  actions: int8 (B,K,3S).
  * done_step[b] (int32) = first step index whose post-state is all zero, or -1.
  * Replaces SyntheticDemoDataset._take_actions (datasets.py:144-153) / K calls of tg_step_i8. */
@@ -94,21 +80,25 @@ int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* act
 
 /* K in-place steps in ONE launch, for action blocks that become available step by step -- a device-side producer
  * (the policy network choosing the next action from the state, act.py:182-183 / training.py:249-255) or a host
- * thread writing through mapped memory.  Same results as K calls of tg_step_i8(state, state, actions[k], done[k], ...);
+ * thread that releases steps through copies / fills enqueued on another stream.  ready, progress, status, actions and
+ * done are DEVICE memory: the stepper polls and publishes with agent-scope (sc1) accesses, which do not order against
+ * a host thread writing through mapped memory.  Same results as K calls of tg_step_i8(state, state, actions[k], done[k], ...);
  * what it removes is the dependent-launch boundary between two steps (1.55 us on MI355X, more than the step itself
  * at S=4, B=65 536): the stepper stays resident, keeps every game's state in registers and per step only polls,
  * reads 12 token bytes per game and writes the new state through.
  *   actions: int8 (K,B,3S), STEP-major.  ready: uint32 (K) or NULL; step k reads its block once ready[k] != 0
- *   (the producer writes the block, then ready[k], with release semantics at agent scope or wider); NULL = every
+ *   (the producer -- a kernel or a copy on this device -- writes the block, then ready[k]; stream order or a release at
+   agent scope makes the block visible first); NULL = every
  *   block is valid at launch.  done: uint8 (K,B), done[k][b] as tg_step_i8 would report after step k.
  *   progress: uint32 (n_units) or NULL; the games are owned by n_units wavefronts, unit u = games
  *   [u*games_per_unit, (u+1)*games_per_unit) (tg_step_stream_layout); once the state and done[k] of its games are
  *   visible to other agents (write-through stores, drained) unit u stores k+1 into progress[u].
  *   status: uint32 (1) or NULL, set to 1 if a wavefront gave up waiting for a ready word (bounded spin, ~1 s).
  * No wavefront ever waits for another one, so the launch itself cannot deadlock; a producer that waits for the WHOLE
- * batch before releasing the next step additionally needs every unit resident at once: S = 4 up to 2^20 games on 256
- * CUs (tg_step_stream_layout refuses more), S = 16 (one wavefront per game, the 4 KiB of a game in registers) up to
- * 32 games per CU = 8 192 on 256 CUs.  S = 4 and S = 16 in this build (TG_ERR_UNSUPPORTED otherwise), states 16-byte
+ * batch before releasing the next step additionally needs every unit resident at once: at S = 4
+ * tg_step_stream_layout chooses the games per wavefront so that this holds and refuses batches beyond what the
+ * device keeps resident (about 4.5e5 games on the 256 CUs of an MI355X); S = 16 (one wavefront per game, the 4 KiB of
+ * a game in registers) holds 32 games per CU = 8 192 on 256 CUs, beyond that the units run in rounds.  S = 4 and S = 16 in this build (TG_ERR_UNSUPPORTED otherwise), states 16-byte
  * aligned (S = 16: actions too).  This is a separate entry with its own metric: the single-step figures of tg_step_i8
  * never include it. */
 int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8_t* overflow,
@@ -211,6 +201,17 @@ int tg_change_basis_i8(const int8_t* state_in, const int32_t* basis, int8_t* sta
 int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_dtype, int64_t B, int S,
                    int T, int head_slot, float t_step, int64_t frame_stride_bytes,
                    int64_t game_stride_bytes, tg_stream_t stream);
+
+/* N1, fused: ONE env step on the history ring and the model input of the NEW state in one call -- what extend_tree
+ * does between two network evaluations (get_child_states' history shift, act.py:271-274, then the (B,T,S,S,S) tensor
+ * and get_scalars for fwd_infer, act.py:178-182).  The step reads ring slot head_slot and writes the new head into slot
+ * (head_slot + 1) mod T (T = 1: in place); done / overflow as tg_step_i8; out[b][0] = float(new head), out[b][f] =
+ * float(ring[b][(head_slot + 1 - f) mod T]); out_dtype, scalars, strides as tg_emit_frames.  The caller's head slot
+ * afterwards is (head_slot + 1) mod T.  At S = 4 this is one kernel (the new head and the old head are emitted from
+ * registers); other sizes run tg_step_i8 and tg_emit_frames inside the call. */
+int tg_step_emit(int8_t* ring, const int8_t* actions, void* out, float* scalars, uint8_t* done, uint8_t* overflow,
+                 int out_dtype, int64_t B, int S, int T, int head_slot, float t_step, int64_t frame_stride_bytes,
+                 int64_t game_stride_bytes, int shift, tg_stream_t stream);
 
 /* N2, transposition-table key.  hash_out[b] (uint64) = H(state[b]): with the S^3 bytes zero-padded
  * to 8-byte little-endian words w_k, H = fmix64( (sum_k fmix64(w_k + (k+1)*0x9E3779B97F4A7C15))

@@ -6,8 +6,8 @@ import ctypes as C
 import os
 from pathlib import Path
 
-# TG_LIB_VARIANT=ab selects the A/B build (libtensorgame_ab.so, -DTG_AB_SWITCHES: the TG_* environment
-# switches, the first-generation kernels and tg_step_sparse_i8) -- measurement and A/B tests only.
+# TG_LIB_VARIANT=ab selects the A/B build (libtensorgame_ab.so, -DTG_AB_SWITCHES: the same entry points plus the
+# TG_* environment switches that force a kernel variant) -- measurement and A/B tests only.
 _VARIANT = os.environ.get("TG_LIB_VARIANT", "")  # "", "ab", or "stamps" (ab + in-kernel time stamps; diagnostics only)
 AB_VARIANT = _VARIANT in ("ab", "stamps")
 LIB_PATH = Path(__file__).resolve().parent / "lib" / {"ab": "libtensorgame_ab.so", "stamps": "libtensorgame_stamps.so"}.get(
@@ -50,12 +50,11 @@ SIGNATURES = {
     "tg_sample_basis_i8": [_p, _p, _p, _i64, _i, _p, _p, _i, _u64, _u64, _p],
     "tg_change_basis_i8": [_p, _p, _p, _p, _i64, _i, _i64, _p],
     "tg_emit_frames": [_p, _p, _p, _i, _i64, _i, _i, _i, C.c_float, _i64, _i64, _p],
+    "tg_step_emit": [_p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _i, C.c_float, _i64, _i64, _i, _p],
     "tg_hash_u64": [_p, _p, _i64, _i, _i64, _p],
     "tg_seen_u64": [_p, _p, _i64, _p, _p, _p, _i64, _i, _p],
     "tg_rank_i32": [_p, _p, _i64, _i, _i64, _p],
 }
-if AB_VARIANT:
-    SIGNATURES["tg_step_sparse_i8"] = [_p, _p, _p, _p, _p, _i64, _i, _i64, _i, _p]
 
 
 def _preload_torch_hip_runtime() -> None:

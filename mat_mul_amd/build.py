@@ -6,9 +6,8 @@ is newer) and the objects are linked into ``mat_mul_amd/lib/libtensorgame.so``.
 Two variants:
   * the PRODUCT library (default): no environment switches, no measurement-only kernels;
   * the A/B library ``libtensorgame_ab.so`` (``build(ab=True)``, compiled with -DTG_AB_SWITCHES): the
-    same sources plus the getenv A/B switches, the first-generation 32-bit cursor kernels and the
-    nnz-carrying sparse step (tg_step_sparse_i8).  Loaded only when TG_LIB_VARIANT=ab is set
-    (tests/test_gpu_parity.py::test_ab_switch_paths_stay_exact, tools/).
+    same sources and entry points plus the getenv switches that force a kernel variant.  Loaded only when
+    TG_LIB_VARIANT=ab is set (tests/test_gpu_ab_library.py, tools/).
 """
 from __future__ import annotations
 

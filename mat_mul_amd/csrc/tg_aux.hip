@@ -433,7 +433,7 @@ int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_dtype,
   const int64_t total = B * T * N;
   // outputs the Infinity Cache can hold stay there for their reader (tools measurement on expand's children: nt stores
   // of a 34 MB output speed the producer up and slow the consumer down by the same amount)
-  const bool nt = total * (out_dtype ? 2 : 4) >= tg::kStreamOutBytes;
+  const bool nt = total * (out_dtype ? 2 : 4) >= tg::kStreamOutBytes || TG_SWITCH("TG_EMIT_NT");  // (A/B switch: tests)
   if (vec16 && N >= 2 && total < (1ll << 31)) {
     // (the 32-bit loop variable passes `total` by at most one grid stride, 2^26 elements: no wrap)
     const uint32_t mN = static_cast<uint32_t>(((1ull << 32) + N - 1) / N);

@@ -522,7 +522,9 @@ __global__ __launch_bounds__(CB) void change_basis_kernel(const int8_t* in, cons
 //                      x = (hi << 8) + lo; written IN PLACE over the tile's own block as [c][b][i] (i fastest).
 //   stage 3 (mode 1):  T'[a][b][c] = sum_i Y2[(c,b)][i] A[a][i]   one tile per c (rows b); int32 results, range
 //                      checked, low bytes into the output image.
-// Exact while every basis entry fits int8 and the intermediates fit 16 bits: max|X| rc <= 32767 and max|X| rc rb <= 32767
+// Exact while every basis entry fits int8 and the intermediates fit the two byte planes: max|X| rc <= 32639 and
+// max|X| rc rb <= 32639 (a value y is split as lo = signed low byte, hi = (y + 128) >> 8 stored as int8: from y = 32640
+// on hi would be 128 and wrap)
 // with rc, rb the largest absolute row sums of C and B (checked per game from the data); any other game is done by the
 // vector form above (change_basis_game) inside the same launch.
 // ---------------------------------------------------------------------------------------------------------------
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(64 * NW) void change_basis_mfma_kernel(const int8_t
     TG_CSTAMP(cst++);  // image + matrices + sums done
     const int rb = red[2], rc = red[3], mx0 = red[5];  // (the last stage's sums are int32: no condition on A's rows)
     // |Y1| <= mx0 rc and |Y2| <= mx0 rc rb must fit the two byte planes (16 bits); workgroup-uniform
-    const bool eligible = red[0] == 0 && static_cast<int64_t>(mx0) * rc <= 32767 && static_cast<int64_t>(mx0) * rc * rb <= 32767;
+    const bool eligible = red[0] == 0 && static_cast<int64_t>(mx0) * rc <= 32639 && static_cast<int64_t>(mx0) * rc * rb <= 32639;
     if (!eligible) {
       __syncthreads();
       change_basis_game<S, kThreads>(in, basis, out, overflow, g, S, stride, X);

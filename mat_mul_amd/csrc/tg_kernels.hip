@@ -11,13 +11,13 @@
 //   s16_step : S = 16 single step, one wavefront per game, registers only.
 //   packed_* / rows_* (tg_packed.h, tg_rows.h): aligned layouts, 16-byte chunks, int16 pairs.
 //   *_mfma_* (tg_mfma.h): accumulation over many terms on the matrix cores.
-//   team_*   : the first-generation 32-bit cursor kernels; compiled only into the A/B library
-//              (-DTG_AB_SWITCHES, mat_mul_amd/build.py) as a measurement reference.
 //
 // The PRODUCT build reads no environment variable and keeps no mutable host state besides per-device
 // caches of device constants (atomics): TG_SWITCH() is constant false.  The A/B build (-DTG_AB_SWITCHES)
-// turns the TG_* environment switches on and adds team_kernel and tg_step_sparse_i8.
+// turns the TG_* environment switches on.
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 #include <atomic>
 #include <cstdarg>
@@ -33,9 +33,7 @@ namespace tg {
 
 #define TG_MAX_ACTIONS 4096  // K / k / R per call
 
-// STEPS: the in-place step that also maintains the per-game non-zero count (a.done_step doubles as
-// the int32 nnz array, in/out): kernels may then skip LOADING chunks an action does not touch.
-enum Mode { STEP = 0, MANY = 1, EXPAND = 2, GENF = 3, STEPS = 4 };
+enum Mode { STEP = 0, MANY = 1, EXPAND = 2, GENF = 3 };
 
 // Debug aid: workgroups of the packed/rows kernels that fell back to the exact byte-wise form
 // (factors too large for the 16-bit path, or an int8 overflow in step_many).  A silent fallback is
@@ -67,6 +65,13 @@ struct ApplyArgs {
   uint64_t* keys;        // EXPAND (B,nact), nullable: the 64-bit key of every child (tg_expand_keyed_i8)
 };
 
+// tg_step_i8 at S = 4: from this many bytes of states on a lane awaits its token before it requests its slice
+// (s4_step_kernel<.., TW>; placed by tools/step_sizes_bench.py sweeps)
+constexpr int64_t kS4TokenWaitBytes = 384ll << 20;
+
+// tg_step_i8 at S = 16 / 25: the state is read by non-temporal loads for footprints in [from, to)
+constexpr int64_t kNtLoadsFromBytes = 320ll << 20, kNtLoadsToBytes = 1280ll << 20;
+
 // done_step value by which many_mfma_kernel hands a game to the lattice kernels (never a valid result)
 constexpr int32_t kNeedsExact = INT32_MIN;
 
@@ -74,9 +79,8 @@ constexpr int32_t kNeedsExact = INT32_MIN;
 // slow path: any S, any alignment.  One workgroup per game, one byte per thread-iteration.
 // =============================================================================================
 // One game (index b) by the whole workgroup.  nzf: TG_MAX_ACTIONS bytes of LDS (MANY only).
-template <int MODE_>
+template <int MODE>
 __device__ __forceinline__ void slow_game(const ApplyArgs& a, int64_t b, uint8_t* nzf) {
-  constexpr int MODE = (MODE_ == STEPS) ? STEP : MODE_;  // STEPS: a step plus an exact recount of nnz
   const int S = a.S, S2 = S * S, N = S2 * S, A3 = 3 * S;
   const int tid = threadIdx.x;
   const int8_t* tok = a.actions + b * a.nact * A3;
@@ -112,7 +116,7 @@ __device__ __forceinline__ void slow_game(const ApplyArgs& a, int64_t b, uint8_t
     }
     const int8_t* src = (MODE == GENF) ? nullptr : a.in + b * a.in_stride;
     int8_t* dst = a.out + b * a.out_stride;
-    int nz = 0, ovf = 0, cnt = 0;
+    int nz = 0, ovf = 0;
     for (int e = tid; e < N; e += kBlock) {
       const int i = e / S2, r = e - i * S2, j = r / S, l = r - j * S;
       int acc = (MODE == GENF) ? 0 : src[e];
@@ -132,16 +136,6 @@ __device__ __forceinline__ void slow_game(const ApplyArgs& a, int64_t b, uint8_t
       if constexpr (MODE == GENF) ovf |= (acc + 128);
       dst[e] = static_cast<int8_t>(acc);
       nz |= acc & 255;
-      if constexpr (MODE_ == STEPS) cnt += (acc & 255) != 0;
-    }
-    if constexpr (MODE_ == STEPS) {  // workgroup sum through an LDS word (nzf is 4-byte aligned)
-      int* total = reinterpret_cast<int*>(nzf);
-      __syncthreads();
-      if (tid == 0) *total = 0;
-      __syncthreads();
-      if (cnt) atomicAdd(total, cnt);
-      __syncthreads();
-      if (tid == 0) a.done_step[b] = *total;
     }
     nz = __syncthreads_or(nz);
     ovf = __syncthreads_or(ovf & ~255);
@@ -166,49 +160,8 @@ __global__ __launch_bounds__(kBlock) void slow_kernel(ApplyArgs a) {
 }
 
 // =============================================================================================
-// team path: aligned layouts, 16-byte chunks, factor tokens staged in LDS.
+// helpers of the aligned kernels: 16-byte chunks <-> 32-bit accumulators
 // =============================================================================================
-template <int S, int TS>
-struct Geo {
-  static constexpr int N = S * S * S;
-  static constexpr int NCHUNK = (N + 15) / 16;        // chunk c = bytes [16c, 16c+16) of the game
-  static constexpr int NCH = (NCHUNK + TS - 1) / TS;  // chunks per lane
-  static constexpr int GPB = kBlock / TS;             // games per workgroup
-  static constexpr int TAIL = N % 16;                 // valid bytes of the last chunk (0 = full)
-  static constexpr int FSTRIDE = 3 * S + 1;           // LDS shorts per action: v[S] w[S] u[S] 0
-  static constexpr int ATILE_RAW = 32768 / (GPB * FSTRIDE * 2);
-  static constexpr int ATILE = ATILE_RAW > 128 ? 128 : ATILE_RAW;  // actions staged per LDS tile
-  static constexpr int LDS_BYTES = GPB * ATILE * FSTRIDE * 2;
-  static_assert(TS == 4 || TS == 8 || TS == 16 || TS == 32 || TS == 64 || TS == 256, "team size");
-  static_assert(ATILE >= 1, "LDS tile");
-};
-
-// acc[t] += sgn * u_i v_j w_l for the 16 consecutive elements starting at cursor (i,j,l).
-// F (LDS): v at [0,S), w at [S,2S), u at [2S,3S), and a ZERO at [3S]: a cursor that runs past the
-// last element of the game reads u = 0, so the padding lanes of a tail chunk accumulate nothing.
-template <int S, bool SUB>
-__device__ __forceinline__ void rank1_16(int (&acc)[16], int i, int j, int l, const short* F, int& chg) {
-  int ui = F[2 * S + i];
-  if constexpr (SUB) ui = -ui;
-  int uv = mul24_pinned(ui, F[j]);
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int p = __mul24(uv, F[S + l]);
-    acc[t] += p;
-    chg |= p;
-    if (++l == S) {
-      l = 0;
-      if (++j == S) {
-        j = 0;
-        ++i;
-        ui = F[2 * S + i];
-        if constexpr (SUB) ui = -ui;
-      }
-      uv = mul24_pinned(ui, F[j]);
-    }
-  }
-}
-
 __device__ __forceinline__ void unpack16(const uint4& q, int (&acc)[16]) {
   const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -252,187 +205,6 @@ __device__ __forceinline__ void store_chunk(int8_t* p, const uint4& q, bool tail
   *reinterpret_cast<uint4*>(p) = q;
 }
 
-#ifdef TG_AB_SWITCHES
-// The exact 32-bit form: any factor magnitude.  Body of team_kernel, and the fallback of the
-// packed-int16 kernels (tg_packed.h) for games whose factors are too large for 16-bit sums.
-template <int S, int TS, int MODE>
-__device__ __forceinline__ void team_body_i32(const ApplyArgs& a, short* lds, uint8_t* nzf) {
-  using G = Geo<S, TS>;
-  constexpr bool SUB = (MODE != GENF);
-
-  const int tid = threadIdx.x;
-  const int team = tid / TS, lt = tid % TS;
-  int64_t g = static_cast<int64_t>(blockIdx.x) * G::GPB + team;
-  const bool live = g < a.B;
-  if (!live) g = a.B - 1;  // dead teams shadow the last game (uniform barriers), stores predicated off
-  short* const F = lds + team * (G::ATILE * G::FSTRIDE);
-  const int8_t* const tok = a.actions + g * a.nact * (3 * S);
-
-  // chunk ownership and element cursors: chunk c = n*TS + lt covers elements [16c, 16c+16)
-  int ci[G::NCH], cj[G::NCH], cl[G::NCH];
-  bool cv[G::NCH], ctail[G::NCH];
-#pragma unroll
-  for (int n = 0; n < G::NCH; ++n) {
-    const int c = n * TS + lt;
-    cv[n] = c < G::NCHUNK;
-    ctail[n] = (G::TAIL != 0) && (c == G::NCHUNK - 1);
-    const int e0 = 16 * c;
-    ci[n] = e0 / (S * S);
-    const int r = e0 - ci[n] * (S * S);
-    cj[n] = r / S;
-    cl[n] = r - cj[n] * S;
-  }
-
-  // parent / current state chunks
-  uint4 pk[G::NCH];
-#pragma unroll
-  for (int n = 0; n < G::NCH; ++n) {
-    pk[n] = uint4{0, 0, 0, 0};
-    if (MODE != GENF && cv[n]) pk[n] = load_chunk<G::TAIL>(a.in + g * a.in_stride + 16 * (n * TS + lt), ctail[n]);
-  }
-
-  auto stage = [&](int a0, int na) {  // tokens of actions [a0, a0+na) of this team's game -> LDS
-    __syncthreads();
-    for (int r = lt; r < na * 3 * S; r += TS) {
-      const int k = r / (3 * S), pos = r - k * (3 * S);
-      const int val = tok[(a0 + k) * (3 * S) + pos] - a.shift;
-      // token order is u,v,w; LDS order is v,w,u,0
-      const int dst = pos < S ? 2 * S + pos : pos - S;
-      F[k * G::FSTRIDE + dst] = static_cast<short>(val);
-    }
-    for (int k = lt; k < na; k += TS) F[k * G::FSTRIDE + 3 * S] = 0;
-    __syncthreads();
-  };
-
-  int ovf = 0;
-
-  if constexpr (MODE == STEP) {
-    stage(0, 1);
-    uint32_t nz = 0;
-    int chg = 0;
-#pragma unroll
-    for (int n = 0; n < G::NCH; ++n) {
-      if (!cv[n]) continue;
-      int acc[16];
-      unpack16(pk[n], acc);
-      rank1_16<S, true>(acc, ci[n], cj[n], cl[n], F, chg);
-      pk[n] = pack16(acc, nz, ovf);
-      if (live) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * (n * TS + lt), pk[n], ctail[n]);
-    }
-    bool any_nz, any_ovf;
-    if constexpr (TS == 256) {
-      any_nz = __syncthreads_or(nz != 0);
-      any_ovf = __syncthreads_or((ovf & ~255) != 0);
-    } else {
-      any_nz = team_any<TS>(nz != 0);
-      any_ovf = team_any<TS>((ovf & ~255) != 0);
-    }
-    if (lt == 0 && live) {
-      a.done[g] = any_nz ? 0 : 1;
-      if (a.overflow && any_ovf) a.overflow[g] = 1;
-    }
-  } else if constexpr (MODE == MANY || MODE == GENF) {
-    int acc[G::NCH][16];
-#pragma unroll
-    for (int n = 0; n < G::NCH; ++n) unpack16(pk[n], acc[n]);
-    int done_step = -1;
-    if constexpr (MODE == MANY && TS == 256) {
-      for (int k = tid; k < a.nact; k += kBlock) nzf[k] = 0;
-    }
-    for (int a0 = 0; a0 < a.nact; a0 += G::ATILE) {
-      const int na = min(G::ATILE, a.nact - a0);
-      stage(a0, na);
-      for (int k = 0; k < na; ++k) {
-        int chg = 0;
-        uint32_t nz = 0;
-#pragma unroll
-        for (int n = 0; n < G::NCH; ++n) {
-          if (!cv[n]) continue;
-          rank1_16<S, SUB>(acc[n], ci[n], cj[n], cl[n], F + k * G::FSTRIDE, chg);
-          if constexpr (MODE == MANY) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-              nz |= static_cast<uint32_t>(acc[n][t]);
-              ovf |= acc[n][t] + 128;
-            }
-          }
-        }
-        if constexpr (MODE == MANY) {
-          if constexpr (TS == 256) {
-            if (nz & 255) nzf[a0 + k] = 1;
-          } else {
-            if (!team_any<TS>((nz & 255) != 0) && done_step < 0) done_step = a0 + k;
-          }
-        }
-      }
-    }
-    uint32_t nz = 0;
-#pragma unroll
-    for (int n = 0; n < G::NCH; ++n) {
-      if (!cv[n]) continue;
-      pk[n] = pack16(acc[n], nz, ovf);  // GENF: the only range check (sum narrowed once)
-      if (live) store_chunk<G::TAIL>(a.out + g * a.out_stride + 16 * (n * TS + lt), pk[n], ctail[n]);
-    }
-    bool any_ovf;
-    if constexpr (TS == 256) {
-      any_ovf = __syncthreads_or((ovf & ~255) != 0);  // also orders the nzf writes
-      if (MODE == MANY && tid == 0) {
-        for (int k = 0; k < a.nact; ++k)
-          if (!nzf[k]) { done_step = k; break; }
-      }
-    } else {
-      any_ovf = team_any<TS>((ovf & ~255) != 0);
-    }
-    if (lt == 0 && live) {
-      if constexpr (MODE == MANY) a.done_step[g] = done_step;
-      if (a.overflow && any_ovf) a.overflow[g] = 1;
-    }
-  } else {  // EXPAND
-    for (int a0 = 0; a0 < a.nact; a0 += G::ATILE) {
-      const int na = min(G::ATILE, a.nact - a0);
-      stage(a0, na);
-      for (int k = 0; k < na; ++k) {
-        const int64_t child = g * a.nact + a0 + k;
-        uint32_t nz = 0;
-        int chg = 0, covf = 0;
-#pragma unroll
-        for (int n = 0; n < G::NCH; ++n) {
-          if (!cv[n]) continue;
-          int acc[16];
-          unpack16(pk[n], acc);
-          rank1_16<S, true>(acc, ci[n], cj[n], cl[n], F + k * G::FSTRIDE, chg);
-          const uint4 q = pack16(acc, nz, covf);
-          if (live) store_chunk<G::TAIL>(a.out + child * a.out_stride + 16 * (n * TS + lt), q, ctail[n]);
-        }
-        bool any_nz, any_chg, any_ovf;
-        if constexpr (TS == 256) {
-          any_nz = __syncthreads_or(nz != 0);
-          any_chg = __syncthreads_or(chg != 0);
-          any_ovf = __syncthreads_or((covf & ~255) != 0);
-        } else {
-          any_nz = team_any<TS>(nz != 0);
-          any_chg = team_any<TS>(chg != 0);
-          any_ovf = team_any<TS>((covf & ~255) != 0);
-        }
-        if (lt == 0 && live) {
-          a.done[child] = any_nz ? 0 : 1;
-          if (a.changed) a.changed[child] = any_chg ? 1 : 0;
-          if (a.overflow && any_ovf) a.overflow[child] = 1;
-        }
-      }
-    }
-  }
-}
-
-template <int S, int TS, int MODE>
-__global__ __launch_bounds__(kBlock) void team_kernel(ApplyArgs a) {
-  __shared__ short lds[Geo<S, TS>::LDS_BYTES / 2];
-  __shared__ uint8_t nzf[(MODE == MANY && TS == 256) ? TG_MAX_ACTIONS : 4];
-  team_body_i32<S, TS, MODE>(a, lds, nzf);
-}
-
-#endif  // TG_AB_SWITCHES
-
 #include "tg_packed.h"
 #include "tg_rows.h"
 #include "tg_mfma.h"
@@ -474,18 +246,34 @@ __device__ __forceinline__ void s4_rank1(int (&acc)[16], const S4Factors& f, int
   }
 }
 
-// One step on one 16-byte slice (S = 4, lane q owns slice i = q), the body of tg_step_i8 and of the
-// child-per-team tg_expand_i8.  Packed form: the slice as 8 sign-extended int16 pairs, 8 saturating
-// v_pk_mad_i16.  No range check on the factors is needed: with |factor| <= 255 (int8 token,
-// |shift| <= 127, else the 32-bit form) u*v is formed exactly and SATURATES beyond int16, and so does
-// (u v) w + x, so every case the 16-bit form cannot represent ends outside [-128, 127] -- exactly the
-// cases where the true result overflows int8 (|x| <= 128 cannot bring a saturated product back).
-// Those lanes redo their slice in 32-bit (wrapped bytes + flag, as the contract wants); all others
-// are exact.  ~55 VALU ops per lane instead of ~105: at cfg2 the four wavefronts of a SIMD all get
-// their data at the same time, so the arithmetic is on the launch's critical path.
+// One step on one 16-byte slice (S = 4, lane q owns slice i = q), the body of tg_step_i8, of the child-per-team
+// tg_expand_i8 and of the streamed stepper.  Packed form: the slice as 8 int16 pairs, 8 saturating v_pk_mad_i16.
+// No range check on the factors is needed: with |factor| <= 255 (int8 token, |shift| <= 127, else the 32-bit form)
+// u*v is formed exactly and SATURATES beyond int16, and so does (u v) w + x, so every case the 16-bit form cannot
+// represent ends outside the int8 range -- exactly the cases where the true result overflows int8 (|x| <= 255 cannot
+// bring a saturated product back).  Those lanes redo their slice in 32-bit (wrapped bytes + flag, as the contract
+// wants); all others are exact.
+// Round 3: the state enters BIASED -- byte b as b + 128 in [0, 255], zero-extended (x ^ 0x80808080, two v_perm_b32) --
+// so "the result fits int8" is "the high byte of every int16 result is zero": the range test is an OR of the eight
+// results (4 v_or3) instead of eight v_pk_add_u16 + the ORs, at the price of one XOR per output dword: 51 VALU ops per
+// lane on the data path instead of 55 (3.58 against 3.69 us per launch at 131 072 games with the one-dword token load
+// of s4_step_kernel, tools/s4_share_probe.hip: with 8 wavefronts per SIMD the arithmetic is on the launch's critical
+// path).
 // nz |= result bytes; ovf |= (n + 128) of the 32-bit form only (test ovf & ~255).
-__device__ __forceinline__ uint4 s4_step_slice(const uint4 in_slice, uint32_t du, uint32_t dv, uint32_t dw, int q,
-                                               int shift, uint32_t& nz, int& ovf) {
+// the slice's 16 bytes as eight pairs of b + 128 (zero-extended): P[2d] = (b0, b1), P[2d+1] = (b2, b3) of dword d
+__device__ __forceinline__ void s4_unpack_biased(const uint4& in_slice, uint32_t (&P)[8]) {
+  const uint32_t x[4] = {in_slice.x, in_slice.y, in_slice.z, in_slice.w};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t xb = x[d] ^ 0x80808080u;
+    P[2 * d] = __builtin_amdgcn_perm(0u, xb, 0x0c010c00u);
+    P[2 * d + 1] = __builtin_amdgcn_perm(0u, xb, 0x0c030c02u);
+  }
+}
+
+// the step on an unpacked slice (P from s4_unpack_biased; in_slice again for the rare 32-bit redo)
+__device__ __forceinline__ uint4 s4_step_unpacked(const uint32_t (&P)[8], const uint4& in_slice, uint32_t du, uint32_t dv,
+                                                  uint32_t dw, int q, int shift, uint32_t& nz, int& ovf) {
   const uint32_t shp = (static_cast<uint32_t>(shift) & 0xFFFFu) | (static_cast<uint32_t>(shift) << 16);
   const int ui = shift - __builtin_amdgcn_sbfe(static_cast<int>(du), 8 * q, 8);  // -(u_i)
   const uint32_t uip = __builtin_amdgcn_perm(static_cast<uint32_t>(ui), static_cast<uint32_t>(ui), 0x05040100u);
@@ -496,17 +284,25 @@ __device__ __forceinline__ uint4 s4_step_slice(const uint4 in_slice, uint32_t du
   const uint32_t wB = pk_sub_i16(__builtin_amdgcn_perm(dw, yw, 0x0B070906u), shp);  // (w2, w3)
   const uint32_t uvA = pk_mad_i16_sat(vA, uip, 0u), uvB = pk_mad_i16_sat(vB, uip, 0u);
   uint32_t A[8];
-  unpack_pairs(in_slice, A);
-  A[0] = pk_mad_i16_sat_lo(uvA, wA, A[0]);  // row j = 0: -u v0 in both halves
-  A[1] = pk_mad_i16_sat_lo(uvA, wB, A[1]);
-  A[2] = pk_mad_i16_sat_hi(uvA, wA, A[2]);  // j = 1
-  A[3] = pk_mad_i16_sat_hi(uvA, wB, A[3]);
-  A[4] = pk_mad_i16_sat_lo(uvB, wA, A[4]);  // j = 2
-  A[5] = pk_mad_i16_sat_lo(uvB, wB, A[5]);
-  A[6] = pk_mad_i16_sat_hi(uvB, wA, A[6]);  // j = 3
-  A[7] = pk_mad_i16_sat_hi(uvB, wB, A[7]);
-  uint32_t ovf16 = 0;
-  uint4 pk = pack_pairs(A, nz, ovf16);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {  // row j = d: -u v_j is the low (j even) or high (j odd) half of uvA / uvB
+    const uint32_t uv = d < 2 ? uvA : uvB;
+    if (d & 1) {
+      A[2 * d] = pk_mad_i16_sat_hi(uv, wA, P[2 * d]);
+      A[2 * d + 1] = pk_mad_i16_sat_hi(uv, wB, P[2 * d + 1]);
+    } else {
+      A[2 * d] = pk_mad_i16_sat_lo(uv, wA, P[2 * d]);
+      A[2 * d + 1] = pk_mad_i16_sat_lo(uv, wB, P[2 * d + 1]);
+    }
+  }
+  uint32_t w[4], ovf16 = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    ovf16 |= A[2 * d] | A[2 * d + 1];
+    w[d] = __builtin_amdgcn_perm(A[2 * d + 1], A[2 * d], 0x06040200u) ^ 0x80808080u;
+    nz |= w[d];
+  }
+  uint4 pk{w[0], w[1], w[2], w[3]};
   const bool wide_shift = static_cast<unsigned>(shift + 127) > 254u;  // uniform; factors may exceed 255
   if (__builtin_expect(wide_shift || (ovf16 & 0xFF00FF00u), 0)) {  // rare, per lane: exact 32-bit form of this slice
     const int cur[3] = {static_cast<int>(du), static_cast<int>(dv), static_cast<int>(dw)};
@@ -520,7 +316,233 @@ __device__ __forceinline__ uint4 s4_step_slice(const uint4 in_slice, uint32_t du
   return pk;
 }
 
-template <int MODE, bool NTL = false>
+__device__ __forceinline__ uint4 s4_step_slice(const uint4 in_slice, uint32_t du, uint32_t dv, uint32_t dw, int q,
+                                               int shift, uint32_t& nz, int& ovf) {
+  uint32_t P[8];
+  s4_unpack_biased(in_slice, P);
+  return s4_step_unpacked(P, in_slice, du, dv, dw, q, shift, nz, ovf);
+}
+
+// The game's 12 token bytes as three dwords (u | v | w) in every lane of its 4-lane team from ONE dword load per lane:
+// lane q loads dword min(q, 2) and the team exchanges them by DPP quad broadcasts (three v_mov_b32_dpp).  A
+// global_load_dwordx3 per lane asks the memory pipeline for 48 bytes per game where 12 are distinct; with the token
+// buffers of a rollout coming from beyond L2 that is 0.06 us of a 3.6 us launch at 131 072 games.
+// blk_tok: the (wave-uniform) token base of the workgroup; team: the game's index within the workgroup.
+__device__ __forceinline__ uint32_t s4_team_token_load(const int8_t* blk_tok, int team, int q) {
+  const uint32_t off = __umul24(static_cast<uint32_t>(team), 12u) + 4u * static_cast<uint32_t>(q < 3 ? q : 2);  // scalar base + 32-bit lane offset
+  return *reinterpret_cast<const uint32_t*>(blk_tok + off);
+}
+__device__ __forceinline__ void s4_team_token_bcast(uint32_t mine, uint32_t& du, uint32_t& dv, uint32_t& dw) {
+  du = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(mine), 0x00, 0xf, 0xf, true));  // quad_perm [0,0,0,0]
+  dv = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(mine), 0x55, 0xf, 0xf, true));  // [1,1,1,1]
+  dw = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(mine), 0xAA, 0xf, 0xf, true));  // [2,2,2,2]
+}
+__device__ __forceinline__ void s4_team_tokens(const int8_t* blk_tok, int team, int q, uint32_t& du, uint32_t& dv, uint32_t& dw) {
+  s4_team_token_bcast(s4_team_token_load(blk_tok, team, q), du, dv, dw);
+}
+
+// =============================================================================================
+// tg_step_i8 at S = 4: the single step (round 3; s4_kernel below keeps step_many, gen_from_factors and the
+// team-per-parent expand).  4 lanes per game, 16 games per wavefront; one token dword and one 16-byte slice per lane;
+// no LDS, no barrier.  Everything that depends on blockIdx is SCALAR 64-bit math; the per-lane part is a 32-bit offset
+// (host guarantees strides < 2^20).
+//   NTL: the state is read by non-temporal loads (batches beyond the caches: the lines a launch reads are not worth a
+//        place in the Infinity Cache when the next launch's reads evict them anyway);
+//   TW:  a lane waits for its token before it requests its slice.  For batches far beyond the Infinity Cache only: the
+//        wait halves the state requests a wavefront keeps in flight, and the HBM side serves the thinner stream better
+//        (2 GiB of states: 815 -> 793 us, 512 MiB: 202 -> 188; at 256 MiB the same wait costs 8 %).
+// =============================================================================================
+// Its own slim argument block (56 bytes: one scalar-load round trip) and 32-bit strides: with 8 wavefronts per SIMD
+// every instruction in front of the loads, and every VALU instruction behind them, is on the launch's critical path
+// (one VALU instruction per lane = 0.014 us of a 3.6 us launch at 131 072 games).
+struct S4StepArgs {
+  const int8_t* in;
+  int8_t* out;
+  const int8_t* actions;
+  uint8_t* done;
+  uint8_t* overflow;
+  int64_t B;
+  uint32_t stride;  // in == out stride (tg_step_i8 has one), < 2^20
+  int shift;
+};
+
+template <bool NTL, bool TW>
+__global__ __launch_bounds__(kBlock) void s4_step_kernel(S4StepArgs a) {
+  constexpr int GPB = kBlock / 4;  // 64 games per workgroup
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * GPB;
+  const int nlive = static_cast<int>(min(static_cast<int64_t>(GPB), a.B - g0));
+  const int lg_raw = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const bool live = lg_raw < nlive;
+  const int lg = live ? lg_raw : nlive - 1;  // dead lanes shadow the last live game, stores predicated off
+  const uint32_t off = __umul24(static_cast<uint32_t>(lg), a.stride) + 16u * q;
+  const int8_t* const in_blk = a.in + g0 * a.stride;
+  uint32_t du, dv, dw;
+  uint4 pk;
+  auto load_state = [&]() {
+    if constexpr (NTL) {
+      const v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(in_blk + off));
+      pk = uint4{v.x, v.y, v.z, v.w};
+    } else {
+      pk = *reinterpret_cast<const uint4*>(in_blk + off);
+    }
+  };
+  uint32_t P[8];
+  if constexpr (TW) {  // token, wait, slice (the throttled order for batches far beyond the caches)
+    s4_team_tokens(a.actions + g0 * 12, lg, q, du, dv, dw);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    load_state();
+    s4_unpack_biased(pk, P);
+  } else {
+    // The slice FIRST, then the token dword: the states of an in-place rollout sit in L2 / the Infinity Cache, the
+    // step's token block comes from wherever its producer left it -- so the slice is unpacked (12 of the ~50 VALU
+    // operations) while the token is still on its way (vmcnt retires in order).
+    load_state();
+    const uint32_t mine = s4_team_token_load(a.actions + g0 * 12, lg, q);
+    s4_unpack_biased(pk, P);
+    __builtin_amdgcn_sched_barrier(0);
+    s4_team_token_bcast(mine, du, dv, dw);
+  }
+  uint32_t nz = 0;
+  int ovf = 0;
+  pk = s4_step_unpacked(P, pk, du, dv, dw, q, a.shift, nz, ovf);
+  // (skipping the store of untouched slices, as the S >= 9 kernels do in place, is SLOWER here: 16-byte holes inside
+  // 64-byte games turn full-line writes into partial ones -- 2.83 -> 3.05 us at BASELINE config 2)
+  if (live) *reinterpret_cast<uint4*>(a.out + g0 * a.stride + off) = pk;
+  const bool any_nz = team_any<4>(nz != 0);
+  if (q == 0 && live) (a.done + g0)[lg] = any_nz ? 0 : 1;
+  // the flag is sticky and only ever set to 1: a lane whose slice overflowed stores it itself (rare), so the common
+  // path carries no team reduction for it
+  if (__builtin_expect((ovf & ~255) != 0, 0) && a.overflow && live) (a.overflow + g0)[lg] = 1;
+}
+
+// =============================================================================================
+// tg_step_emit at S = 4 ("a fused step + emit model input kernel removes a full extra pass over the
+// state"): one env step on the history ring AND the (B,T,4,4,4) float model input of the new state in one launch.
+// The step writes the new head into ring slot (head+1) mod T; frame 0 of the output comes from the registers that hold
+// it, frame 1 (the old head) from the registers the step read it into, older frames from the ring.
+// Lane mapping: 4 lanes per game as in s4_step_kernel, but TRANSPOSED -- lane q holds dword q of every slice, i.e. the
+// elements (i = d, j = q, l = 0..3) for d = 0..3 -- so that the four conversions of dword d leave as 16 contiguous
+// output bytes per lane and 64 contiguous bytes per team (float32; 32 bytes for the 16-bit types): whole sectors per
+// store instruction instead of 16-byte pieces 64 bytes apart.  The arithmetic is s4_step_slice's with the roles of u
+// and v exchanged (the lane constant is -v_q, the dword index selects u_d).
+// =============================================================================================
+struct StepEmitArgs {
+  int8_t* ring;
+  const int8_t* actions;
+  void* out;
+  float* scalars;
+  uint8_t* done;
+  uint8_t* overflow;
+  int64_t B;
+  int64_t frame_stride;
+  int64_t game_stride;
+  int T;
+  int head;
+  int shift;
+  float t_step;
+};
+
+// four int8 -> four float32 at dst (16 bytes); NT: non-temporal store
+template <bool NT>
+__device__ __forceinline__ void s4_emit_f32(float* dst, uint32_t w) {
+  const uint4 o{__float_as_uint(static_cast<float>(sbyte(w, 0))), __float_as_uint(static_cast<float>(sbyte(w, 1))),
+                __float_as_uint(static_cast<float>(sbyte(w, 2))), __float_as_uint(static_cast<float>(sbyte(w, 3)))};
+  if constexpr (NT) store16_nt(dst, o);
+  else *reinterpret_cast<uint4*>(dst) = o;
+}
+// four int8 -> two dwords of two 16-bit floats each
+template <typename OutT>
+__device__ __forceinline__ uint2 s4_cvt16(uint32_t w) {
+  const float f0 = static_cast<float>(sbyte(w, 0)), f1 = static_cast<float>(sbyte(w, 1)), f2 = static_cast<float>(sbyte(w, 2)),
+              f3 = static_cast<float>(sbyte(w, 3));
+  uint32_t lo, hi;
+  if constexpr (std::is_same<OutT, __half>::value) {
+    typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t x = __builtin_amdgcn_cvt_pkrtz(f0, f1), y = __builtin_amdgcn_cvt_pkrtz(f2, f3);  // |x| <= 128: exact
+    __builtin_memcpy(&lo, &x, 4);
+    __builtin_memcpy(&hi, &y, 4);
+  } else {  // bfloat16 = the upper half of the float32 (at most 8 significant bits: exact)
+    lo = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+    hi = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+  }
+  return uint2{lo, hi};
+}
+// One frame (the lane's dwords y[d] = elements (i = d, j = q, l = 0..3)) -> the output, `frame` = element (0, 0, 0) of
+// this game's frame.  float32: dword d of lane q is 16 output bytes at element 16 d + 4 q -- 64 contiguous bytes per
+// team and instruction.  16-bit types: a dword is only 8 output bytes, so the lanes of a PAIR (q, q ^ 1) exchange
+// dwords (DPP quad_perm [1,0,3,2]) and the even lane stores rows d = 0, 2, the odd lane rows d = 1, 3, each as 16
+// bytes covering (j = 2 p, 2 p + 1): again 16-byte stores and 64 contiguous bytes per team and instruction (8-byte
+// stores ran the 2^20-game case at 0.65 of step + emit_frames).
+template <typename OutT, bool NT>
+__device__ __forceinline__ void s4_emit_frame(OutT* frame, const uint32_t (&y)[4], int q) {
+  if constexpr (sizeof(OutT) == 4) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) s4_emit_f32<NT>(frame + 16 * d + 4 * q, y[d]);
+  } else {
+    const bool odd = (q & 1) != 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // rows d = 2 h (even lane) / 2 h + 1 (odd lane)
+      const uint32_t give = odd ? y[2 * h] : y[2 * h + 1];   // what the partner stores of mine
+      const uint32_t got = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(give), 0xB1, 0xf, 0xf, true));
+      const uint32_t mine = odd ? y[2 * h + 1] : y[2 * h];
+      const uint2 a = s4_cvt16<OutT>(odd ? got : mine), b = s4_cvt16<OutT>(odd ? mine : got);  // (j = 2p, j = 2p + 1)
+      const uint4 o{a.x, a.y, b.x, b.y};
+      OutT* const dst = frame + 16 * (2 * h + (odd ? 1 : 0)) + 4 * (q & ~1);
+      if constexpr (NT) store16_nt(dst, o);
+      else *reinterpret_cast<uint4*>(dst) = o;
+    }
+  }
+}
+
+template <typename OutT, bool NT>
+__global__ __launch_bounds__(kBlock) void s4_step_emit_kernel(StepEmitArgs a) {
+  constexpr int GPB = kBlock / 4;
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * GPB;
+  const int nlive = static_cast<int>(min(static_cast<int64_t>(GPB), a.B - g0));
+  const int lg_raw = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const bool live = lg_raw < nlive;
+  const int lg = live ? lg_raw : nlive - 1;
+  uint32_t du, dv, dw;
+  s4_team_tokens(a.actions + g0 * 12, lg, q, du, dv, dw);
+  const int64_t g = g0 + lg;
+  int8_t* const game = a.ring + g * a.game_stride;
+  const int nxt = a.head + 1 < a.T ? a.head + 1 : 0;
+  const int8_t* const src = game + a.head * a.frame_stride + 4 * q;
+  uint32_t x[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) x[d] = *reinterpret_cast<const uint32_t*>(src + 16 * d);  // (i = d, j = q, l = 0..3)
+  uint32_t nz = 0;
+  int ovf = 0;
+  // u and v exchanged: the lane's constant is -v_q, dword d takes u_d
+  const uint4 nw = s4_step_slice(uint4{x[0], x[1], x[2], x[3]}, dv, du, dw, q, a.shift, nz, ovf);
+  const uint32_t y[4] = {nw.x, nw.y, nw.z, nw.w};
+  // (`live` is uniform over a team, so the pair exchange of the 16-bit path stays inside the active lanes)
+  OutT* const out = static_cast<OutT*>(a.out) + g * (a.T * 64);
+  if (live) {
+    int8_t* const dst = game + nxt * a.frame_stride + 4 * q;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) *reinterpret_cast<uint32_t*>(dst + 16 * d) = y[d];
+    s4_emit_frame<OutT, NT>(out, y, q);                    // frame 0: the new head
+    if (a.T > 1) s4_emit_frame<OutT, NT>(out + 64, x, q);  // frame 1: the old head
+    int slot = a.head;
+    for (int f = 2; f < a.T; ++f) {                        // older frames from the ring
+      slot = slot > 0 ? slot - 1 : a.T - 1;
+      const int8_t* const old = game + slot * a.frame_stride + 4 * q;
+      uint32_t z[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) z[d] = *reinterpret_cast<const uint32_t*>(old + 16 * d);
+      s4_emit_frame<OutT, NT>(out + 64 * f, z, q);
+    }
+  }
+  const bool any_nz = team_any<4>(nz != 0);
+  if (q == 0 && live) {
+    a.done[g] = any_nz ? 0 : 1;
+    if (a.scalars) a.scalars[g] = a.t_step;
+  }
+  if (__builtin_expect((ovf & ~255) != 0, 0) && a.overflow && live) a.overflow[g] = 1;
+}
+
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
   // Addressing: everything that depends on blockIdx is SCALAR 64-bit math (SALU); the per-lane
   // part is a small 32-bit offset (host guarantees strides < 2^20).  At the BASELINE cfg2 shape
@@ -531,43 +553,19 @@ __global__ __launch_bounds__(kBlock) void s4_kernel(ApplyArgs a) {
   const int lg_raw = threadIdx.x >> 2, q = threadIdx.x & 3;
   const bool live = lg_raw < nlive;
   const int lg = live ? lg_raw : nlive - 1;  // dead lanes shadow the last live game, stores predicated off
-  const int nact = (MODE == STEP || MODE == STEPS) ? 1 : a.nact;  // the single-step entries pass 1
+  static_assert(MODE == MANY || MODE == GENF || MODE == EXPAND, "the single step is s4_step_kernel");
+  const int nact = a.nact;
   const int* tok = reinterpret_cast<const int*>(a.actions + g0 * nact * 12) + lg * nact * 3;
   const int8_t* in_blk = a.in + g0 * a.in_stride;
   const uint32_t in_off = __umul24(lg, static_cast<uint32_t>(a.in_stride)) + 16u * q;
   uint4 pk{0, 0, 0, 0};
-  if constexpr (MODE != GENF) {
-    if constexpr (NTL) {  // (batches beyond the Infinity Cache: see s16_step_kernel)
-      const v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(in_blk + in_off));
-      pk = uint4{v.x, v.y, v.z, v.w};
-    } else {
-      pk = *reinterpret_cast<const uint4*>(in_blk + in_off);
-    }
-  }
+  if constexpr (MODE != GENF) pk = *reinterpret_cast<const uint4*>(in_blk + in_off);
   int ovf = 0;
 
-  if constexpr (MODE == STEP || MODE == STEPS || MODE == MANY || MODE == GENF) {
+  if constexpr (MODE == MANY || MODE == GENF) {
     int8_t* out_blk = a.out + g0 * a.out_stride;
     const uint32_t out_off = __umul24(lg, static_cast<uint32_t>(a.out_stride)) + 16u * q;
-    if constexpr (MODE == STEP || MODE == STEPS) {
-      const uint32_t du = tok[0], dv = tok[1], dw = tok[2];
-      uint32_t nz = 0;
-      pk = s4_step_slice(pk, du, dv, dw, q, a.shift, nz, ovf);
-      // (skipping the store of untouched slices, as packed_kernel does in place, is SLOWER here: 16-byte
-      // holes inside 64-byte games turn full-line writes into partial ones -- 2.83 -> 3.05 us at cfg2)
-      if (live) *reinterpret_cast<uint4*>(out_blk + out_off) = pk;
-      const bool any_nz = team_any<4>(nz != 0);
-      if (q == 0 && live) (a.done + g0)[lg] = any_nz ? 0 : 1;
-      // the flag is sticky and only ever set to 1: a lane whose slice overflowed stores it itself (rare), so the
-      // common path carries no team reduction for it
-      if (__builtin_expect((ovf & ~255) != 0, 0) && a.overflow && live) (a.overflow + g0)[lg] = 1;
-      if constexpr (MODE == STEPS) {  // S=4 reads the whole game anyway: nnz is simply recounted
-        int cnt = count_nonzero_bytes(pk);
-        cnt += __shfl_xor(cnt, 1);
-        cnt += __shfl_xor(cnt, 2);
-        if (q == 0 && live) (a.done_step + g0)[lg] = cnt;
-      }
-    } else {
+    {
       // exact 32-bit form: GENF always; MANY for teams the lattice form below hands over
       auto many_i32 = [&]() {
         int acc[16];
@@ -753,8 +751,8 @@ __global__ __launch_bounds__(kBlock) void s4_expand_kernel(ApplyArgs a, int PB, 
   const int lc = live ? lg : nlc - 1;                      // dead teams shadow the last live child
   const int pl = (lc * recip) >> 16;                       // parent within the workgroup
   const int64_t c0 = p0 * k;                               // first child of the workgroup
-  const int* tok = reinterpret_cast<const int*>(a.actions + c0 * 12) + lc * 3;
-  const uint32_t du = tok[0], dv = tok[1], dw = tok[2];
+  uint32_t du, dv, dw;
+  s4_team_tokens(a.actions + c0 * 12, lc, q, du, dv, dw);
   const uint4 par = *reinterpret_cast<const uint4*>(a.in + p0 * a.in_stride +
                                                     (__umul24(pl, static_cast<uint32_t>(a.in_stride)) + 16u * q));
   uint32_t nz = 0;
@@ -1442,21 +1440,11 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
   const int64_t B = a.B;
   if constexpr (MODE == EXPAND)
     a.stream_out = (B * a.nact * a.out_stride >= kStreamOutBytes || TG_SWITCH("TG_EXPAND_NT")) && !TG_SWITCH("TG_EXPAND_NO_NT");
-#ifdef TG_AB_SWITCHES
-#define TG_TEAM(S_, TS_)                                                                        \
-  do {                                                                                          \
-    const int64_t blocks = (B + Geo<S_, TS_>::GPB - 1) / Geo<S_, TS_>::GPB;                     \
-    if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);              \
-    (void)hipGetLastError(); hipLaunchKernelGGL((team_kernel<S_, TS_, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a); \
-    return check_launch(fn);                                                                    \
-  } while (0)
-#endif
   if (al && a.S == 4 && aligned4(a.actions) && a.in_stride < (1 << 20) && a.out_stride < (1 << 20)) {
     const int64_t blocks = (B * 4 + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
     if constexpr (MODE == EXPAND) {
-      const bool per_parent = TG_SWITCH("TG_S4_EXPAND_PER_PARENT");  // A/B switch for measurements
-      if (a.nact <= 64 && a.out_stride * 64 < (1 << 24) && !per_parent) {
+      if (a.nact <= 64 && a.out_stride * 64 < (1 << 24)) {
         const int PB = 64 / a.nact, recip = (65536 + a.nact - 1) / a.nact;
         const int64_t eblocks = (B + PB - 1) / PB;
         if (eblocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
@@ -1476,25 +1464,31 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
     (void)hipGetLastError();
     if constexpr (MODE == STEP) {
       // Non-temporal state loads from 96 MiB of states on (in place, measured: 64 MiB 23.1 / 24.0 us plain / nt,
-      // 128 MiB 48.6 / 44.9, 192 MiB 71.8 / 65.1, 256 MiB 92.4 / 85.4, 512 MiB 205 / 204): the lines a launch reads
-      // are not worth their place in the Infinity Cache when the next launch's reads evict them anyway.
-      if ((B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S4_NT_LOADS")) && !TG_SWITCH("TG_S4_NO_NT_LOADS")) {
-        hipLaunchKernelGGL((s4_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
-        return check_launch(fn);
-      }
+      // 128 MiB 48.6 / 44.9, 192 MiB 71.8 / 65.1, 256 MiB 92.4 / 85.4, 512 MiB 205 / 202, 1 GiB 432 / 410, 2 GiB
+      // 891 / 820, 4 GiB 1861 / 1666); from kS4TokenWaitBytes on the token is awaited before the slice is requested
+      // (nt loads without / with the wait: 256 MiB 85.6 / 92.2 us, 512 MiB 202.0 / 188.3, 1 GiB 402.5 / 394.8, 1.5 GiB
+      // 611.3 / 580.2, 2 GiB 814.5 / 793.5).
+      const int64_t bytes = B * a.in_stride;
+      const bool nt = (bytes >= (96ll << 20) || TG_SWITCH("TG_S4_NT_LOADS")) && !TG_SWITCH("TG_S4_NO_NT_LOADS");
+      const bool tw = nt && (bytes >= kS4TokenWaitBytes || TG_SWITCH("TG_S4_TOKEN_WAIT")) && !TG_SWITCH("TG_S4_NO_TOKEN_WAIT");
+      const S4StepArgs sa{a.in, a.out, a.actions, a.done, a.overflow, a.B, static_cast<uint32_t>(a.in_stride), a.shift};
+      if (tw) hipLaunchKernelGGL((s4_step_kernel<true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
+      else if (nt) hipLaunchKernelGGL((s4_step_kernel<true, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
+      else hipLaunchKernelGGL((s4_step_kernel<false, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
+      return check_launch(fn);
+    } else {
+      hipLaunchKernelGGL((s4_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+      return check_launch(fn);
     }
-    hipLaunchKernelGGL((s4_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
-    return check_launch(fn);
   }
   // packed int16 path: exact while nact * f^3 <= 32000 for every |factor| <= f (checked on device)
   int flim = 0;
   if constexpr (MODE == MANY) {
     flim = 127;  // lattice form (tg_packed.h): u*v and 256*w must be representable in int16
   } else {
-    const int64_t n = (MODE == GENF) ? a.nact : 1;  // STEP, STEPS, EXPAND: one action per result
+    const int64_t n = (MODE == GENF) ? a.nact : 1;  // STEP, EXPAND: one action per result
     while (flim < 31 && static_cast<int64_t>(flim + 1) * (flim + 1) * (flim + 1) * n <= 32000) ++flim;
   }
-  const bool force_i32 = TG_SWITCH("TG_FORCE_I32");  // A/B switch for measurements
 #define TG_PACKED(S_, TS_)                                                                      \
   do {                                                                                          \
     const int64_t blocks = (B + PGeo<S_, TS_>::GPB - 1) / PGeo<S_, TS_>::GPB;                   \
@@ -1521,7 +1515,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
   if constexpr (MODE == GENF) {
     // the accumulation over R is a dense contraction: matrix cores (tg_mfma.h); u*v must fit int8 (checked
     // on device, per game), the transposed factors of one game must fit LDS
-    if (aligned16(a.out) && a.out_stride % 16 == 0 && a.nact <= 256 && !force_i32 && !no_mfma) {
+    if (aligned16(a.out) && a.out_stride % 16 == 0 && a.nact <= 256 && !no_mfma) {
 #define TG_MFMA_K(S_, KS_)                                                                      \
   do {                                                                                           \
     /* a workgroup's set-up (tile offsets, staging addresses) is a third of one game's work: give every */ \
@@ -1539,9 +1533,8 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
   do {                                                                                           \
     const int Rp = (a.nact + 31) & ~31;                                                          \
     const int ldsb = mfma_lds_bytes<S_>(Rp);                                                     \
-    const bool ks0 = TG_SWITCH("TG_MFMA_KS0");                                                   \
-    if (Rp == 32 && !ks0) TG_MFMA_K(S_, 1);                                                      \
-    if (Rp == 64 && !ks0) TG_MFMA_K(S_, 2);                                                      \
+    if (Rp == 32) TG_MFMA_K(S_, 1);                                                              \
+    if (Rp == 64) TG_MFMA_K(S_, 2);                                                              \
     TG_MFMA_K(S_, 0);                                                                            \
   } while (0)
       if (a.S == 9) TG_MFMA(9);
@@ -1563,7 +1556,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
     // (tools/many_k_sweep.py, profiles/r02_many_k_sweep.txt: the matrix-core pass costs ~44.5 us at S=25 B=4096 and ~41 us at
     //  S=16 B=8192 whatever K is -- staging, the tiles' fixed part, verdict; the lattice kernels 30 / 50 / 52 us at K = 2 / 3 / 4
     //  (S=25), 24 / 35 / 41 / 45 / 55 at K = 8 / 16 / 20 / 24 / 32 (S=16), 58 / 82 / 106 against 88 / 96 / 99 at K = 12 / 24 / 32 (S=9))
-    if (al && a.nact <= 256 && !force_i32 && !no_mfma && (a.S == 9 || a.S == 16 || a.S == 25) && (pays || many_always)) {
+    if (al && a.nact <= 256 && !no_mfma && (a.S == 9 || a.S == 16 || a.S == 25) && (pays || many_always)) {
       const int Rp = (a.nact + 31) & ~31;
 #ifdef TG_AB_SWITCHES
 #define TG_MANY_SET_ABLATE(a) ((a).only_flagged = getenv("TG_MANY_ABLATE") ? atoi(getenv("TG_MANY_ABLATE")) : 0)
@@ -1601,7 +1594,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
   if constexpr (MODE == MANY || MODE == GENF) {
     // odd S, several actions: each lane owns whole rows (tg_rows.h); the LDS transposition is
     // amortised over the actions
-    if (al && flim >= 1 && !force_i32 && !no_rows && a.nact >= 3) {
+    if (al && flim >= 1 && !no_rows && a.nact >= 3) {
       if (a.S == 9) TG_ROWS(9, 64);
       if (a.S == 25) TG_ROWS(25, 256);
     }
@@ -1609,13 +1602,17 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
 #undef TG_ROWS
   const bool no_s16 = TG_SWITCH("TG_NO_S16_DIRECT");  // A/B switch for measurements
   if constexpr (MODE == STEP) {
-    if (al && a.S == 16 && aligned16(a.actions) && !force_i32 && !no_s16) {
+    if (al && a.S == 16 && aligned16(a.actions) && !no_s16) {
       const int64_t blocks = (B + 3) / 4;
       if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
       (void)hipGetLastError();
       // whole-line stores pay from ~100 MiB of states on (measured: 6.0 / 7.0 us at 32 MiB, 26.3 / 25.5 at 128 MiB,
       // 50.3 / 47.0 at 256 MiB, 150 / 128 at 512 MiB, 16-byte stores / whole lines)
-      if ((B * a.in_stride >= (320ll << 20) || TG_SWITCH("TG_S16_NT_LOADS")) && !TG_SWITCH("TG_S16_NO_NT_LOADS"))  // beyond the Infinity Cache (A/B switch: tests)
+      // non-temporal state loads where the Infinity Cache can still assist a pass but not hold it: 320 MiB .. 1.25 GiB
+      // (round 3 sweep, whole lines without / with them: 512 MiB 129.6 / 99.4 us, 1 GiB 257.6 / 230.0, 1.5 GiB 387.0 / 395.7,
+      // 2 GiB 515.5 / 537.3, 4 GiB 1023.5 / 1054.0 -- once the footprint is many times the cache the hint only costs)
+      const bool nt_band = B * a.in_stride >= kNtLoadsFromBytes && B * a.in_stride < kNtLoadsToBytes;
+      if ((nt_band || TG_SWITCH("TG_S16_NT_LOADS")) && !TG_SWITCH("TG_S16_NO_NT_LOADS"))  // (A/B switches: tests)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
       else if ((B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES")) && !TG_SWITCH("TG_S16_NO_LINES"))  // (A/B switch: tests at small batches)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
@@ -1627,7 +1624,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
   const bool no_s25 = TG_SWITCH("TG_NO_S25_DIRECT");  // A/B switch for measurements
   const bool no_s9 = TG_SWITCH("TG_NO_S9_DIRECT");    // A/B switch for measurements
   if constexpr (MODE == STEP) {
-    if (al && a.S == 9 && a.shift >= -127 && a.shift <= 127 && !force_i32 && !no_s9) {
+    if (al && a.S == 9 && a.shift >= -127 && a.shift <= 127 && !no_s9) {
       const int64_t blocks = (B + 15) / 16;  // four wavefronts of four games
       if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
       (void)hipGetLastError();
@@ -1637,7 +1634,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
   }
   if constexpr (MODE == EXPAND) {
     // one 16-lane team per child (s9_step_kernel<EXPAND>): 80 -> 61 us at B = 32 768, k = 8
-    if (al && a.S == 9 && a.shift >= -127 && a.shift <= 127 && !force_i32 && !no_s9 && B * a.nact < 0x7fffffffLL) {
+    if (al && a.S == 9 && a.shift >= -127 && a.shift <= 127 && !no_s9 && B * a.nact < 0x7fffffffLL) {
       const int64_t blocks = (B * a.nact + 15) / 16;
       (void)hipGetLastError();
       hipLaunchKernelGGL(s9_step_kernel<EXPAND>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
@@ -1646,20 +1643,25 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
   }
   if constexpr (MODE == STEP) {
     // (|shift| <= 127: factors within +-255, which the 32-bit redo of s25_step_kernel takes from its int16 tables)
-    if (al && a.S == 25 && a.shift >= -127 && a.shift <= 127 && B <= 0x7fffffffLL && !force_i32 && !no_s25) {
+    if (al && a.S == 25 && a.shift >= -127 && a.shift <= 127 && B <= 0x7fffffffLL && !no_s25) {
       (void)hipGetLastError();
       // as at S=16: whole-line stores once the batch leaves the caches, non-temporal state loads beyond the Infinity
       // Cache (A/B switches: the variants at test sizes)
-      if ((B * a.in_stride >= (320ll << 20) || TG_SWITCH("TG_S25_NT_LOADS")) && !TG_SWITCH("TG_S25_NO_NT_LOADS"))
+      // (round 3 sweep, 16-byte stores / whole lines / whole lines + nt loads: 244 MiB 46.8 / 47.2 / 52.9 us, 488 MiB
+      // 135.4 / 129.9 / 99.0, 977 MiB 279.0 / 273.7 / 210.6, 1.46 GiB 428.5 / 439.6 / 464.4, 1.9 GiB 529.7 / 552.2 / 554.7,
+      // 3.8 GiB 1089 / 1152 / 1247: beyond 1.25 GiB the plain form is the best one again)
+      const int64_t bytes25 = B * a.in_stride;
+      const bool nt_band = bytes25 >= kNtLoadsFromBytes && bytes25 < kNtLoadsToBytes;
+      if ((nt_band || TG_SWITCH("TG_S25_NT_LOADS")) && !TG_SWITCH("TG_S25_NO_NT_LOADS"))
         hipLaunchKernelGGL((s25_step_kernel<true, true>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
-      else if ((B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S25_LINES")) && !TG_SWITCH("TG_S25_NO_LINES"))
+      else if (((bytes25 >= (96ll << 20) && bytes25 < kNtLoadsToBytes) || TG_SWITCH("TG_S25_LINES")) && !TG_SWITCH("TG_S25_NO_LINES"))
         hipLaunchKernelGGL((s25_step_kernel<true, false>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
       else
         hipLaunchKernelGGL((s25_step_kernel<false, false>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
       return check_launch(fn);
     }
   }
-  if (al && flim >= 1 && !force_i32) {
+  if (al && flim >= 1) {
     // S=9: a game is only 46 chunks, so a wavefront takes FOUR games (teams of 16 lanes, 9 active, 6
     // chunks per lane): measured 0.48 of the HBM peak at 2^19 games against 0.43 (TS=32) and 0.29 (TS=64)
     if (a.S == 9) TG_PACKED(9, 16);
@@ -1678,14 +1680,6 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
     if (a.S == 25) TG_PACKED(25, 256);
   }
 #undef TG_PACKED
-#ifdef TG_AB_SWITCHES
-  if constexpr (MODE != STEPS) {  // the 32-bit cursor kernels (A/B reference) have no nnz-carrying step
-    if (al && a.S == 9) TG_TEAM(9, 64);
-    if (al && a.S == 16) TG_TEAM(16, 64);
-    if (al && a.S == 25) TG_TEAM(25, 256);
-  }
-#undef TG_TEAM
-#endif
   (void)hipGetLastError(); hipLaunchKernelGGL((slow_kernel<MODE>), dim3(capped_grid(B)), dim3(kBlock), 0, st, a);
   return check_launch(fn);
 }
@@ -1699,7 +1693,7 @@ int tg_internal_gen_fused(int8_t* target, int8_t* actions, uint8_t* overflow, co
                           hipStream_t st) {
   using namespace tg;
   const char* fn = "tg_gen_demos_i8";
-  if (TG_SWITCH("TG_NO_FUSED_GEN") || TG_SWITCH("TG_NO_MFMA") || TG_SWITCH("TG_FORCE_I32")) return 0;
+  if (TG_SWITCH("TG_NO_FUSED_GEN") || TG_SWITCH("TG_NO_MFMA")) return 0;
   if (!(S == 9 || S == 16 || S == 25) || R > 256 || B == 0) return 0;
   if (!aligned16(target) || stride % 16 != 0) return 0;
   if (!basis) {  // the drawn values are the factors: u * v must fit a byte product, tokens must fit int8
@@ -1799,18 +1793,6 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
   return launch_apply<tg::STEP>("tg_step_i8", a, static_cast<hipStream_t>(stream));
 }
 
-#ifdef TG_AB_SWITCHES
-int tg_step_sparse_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_t* done, uint8_t* overflow,
-                      int64_t B, int S, int64_t game_stride_bytes, int shift, tg_stream_t stream) {
-  if (int rc = validate_common("tg_step_sparse_i8", B, S, game_stride_bytes)) return rc;
-  if (B && (!state || !actions || !nnz || !done)) return fail(TG_ERR_INVALID, "tg_step_sparse_i8: null pointer");
-  if (reinterpret_cast<uintptr_t>(nnz) & 3) return fail(TG_ERR_INVALID, "tg_step_sparse_i8: nnz must be 4-byte aligned");
-  tg::ApplyArgs a{state, state, actions, done, nnz, nullptr, overflow, B,
-                  game_stride_bytes, game_stride_bytes, S, 1, shift};
-  return launch_apply<tg::STEPS>("tg_step_sparse_i8", a, static_cast<hipStream_t>(stream));
-}
-#endif  // TG_AB_SWITCHES
-
 /* units (wavefronts) and games per unit of tg_step_stream_i8 for a batch of B games, or a negative TG_ERR_* */
 int tg_step_stream_layout(int64_t B, int S, int64_t* n_units, int* games_per_unit) {
   if (B < 0) return fail(TG_ERR_INVALID, "tg_step_stream_layout: B < 0");
@@ -1821,16 +1803,27 @@ int tg_step_stream_layout(int64_t B, int S, int64_t* n_units, int* games_per_uni
     if (games_per_unit) *games_per_unit = 1;
     return TG_OK;
   }
-  // S = 4: every wavefront must be resident at once when the producer waits for the whole batch: 8 workgroups of 4
-  // wavefronts per CU at most, so larger batches give each wavefront more games (16 NG, NG <= 8)
-  const int64_t cap = static_cast<int64_t>(device_cu_count()) * 32;
-  int ng = 1;
-  while (ng < 8 && (B + 16 * ng - 1) / (16 * ng) > cap) ng *= 2;
-  if ((B + 16 * ng - 1) / (16 * ng) > cap)
-    return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: B=%lld exceeds %lld games resident at once", (long long)B, (long long)(cap * 128));
-  if (n_units) *n_units = (B + 16 * ng - 1) / (16 * ng);
-  if (games_per_unit) *games_per_unit = 16 * ng;
-  return TG_OK;
+  // S = 4: every wavefront must be resident at once when the producer waits for the whole batch.  How many a CU holds
+  // depends on the variant's registers (NG games x 16 per wavefront: NG = 1, 2 run 8 workgroups per CU, NG = 4 seven,
+  // NG = 8 three on gfx950), so the cap is taken per variant from the occupancy of ITS kernel on THIS device; the
+  // smallest NG whose units all fit is chosen.
+  static OccupancySlots occ1, occ2, occ4, occ8;
+  const int64_t cus = device_cu_count();
+  const int64_t cap[4] = {cus * 4 * resident_per_cu(tg::s4_stream_kernel<1>, 0, occ1), cus * 4 * resident_per_cu(tg::s4_stream_kernel<2>, 0, occ2),
+                          cus * 4 * resident_per_cu(tg::s4_stream_kernel<4>, 0, occ4), cus * 4 * resident_per_cu(tg::s4_stream_kernel<8>, 0, occ8)};
+  int64_t most = 0;
+  for (int t = 0; t < 4; ++t) {
+    const int ng = 1 << t;
+    const int64_t units = (B + 16 * ng - 1) / (16 * ng);
+    if (units <= cap[t]) {
+      if (n_units) *n_units = units;
+      if (games_per_unit) *games_per_unit = 16 * ng;
+      return TG_OK;
+    }
+    most = cap[t] * 16 * ng > most ? cap[t] * 16 * ng : most;
+  }
+  return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: B=%lld exceeds the %lld games this device keeps resident at once",
+              (long long)B, (long long)most);
 }
 
 int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8_t* overflow, const uint32_t* ready,
@@ -1915,6 +1908,51 @@ int tg_expand_keyed_i8(const int8_t* state_in, int8_t* state_out, const int8_t* 
                        int64_t in_stride_bytes, int64_t out_stride_bytes, int shift, tg_stream_t stream) {
   return expand_common("tg_expand_keyed_i8", state_in, state_out, actions, done, changed, overflow, keys_out, B, S, k,
                        in_stride_bytes, out_stride_bytes, shift, stream);
+}
+
+int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_dtype, int64_t B, int S, int T, int head_slot,
+                   float t_step, int64_t frame_stride_bytes, int64_t game_stride_bytes, tg_stream_t stream);  // tg_aux.hip
+
+int tg_step_emit(int8_t* ring, const int8_t* actions, void* out, float* scalars, uint8_t* done, uint8_t* overflow,
+                 int out_dtype, int64_t B, int S, int T, int head_slot, float t_step, int64_t frame_stride_bytes,
+                 int64_t game_stride_bytes, int shift, tg_stream_t stream) {
+  const char* fn = "tg_step_emit";
+  if (int rc = validate_common(fn, B, S, frame_stride_bytes)) return rc;
+  if (T < 1 || T > 64 || head_slot < 0 || head_slot >= T)
+    return fail(TG_ERR_INVALID, "%s: need 1 <= T <= 64 and 0 <= head_slot < T", fn);
+  if (game_stride_bytes < static_cast<int64_t>(T - 1) * frame_stride_bytes + static_cast<int64_t>(S) * S * S)
+    return fail(TG_ERR_INVALID, "%s: game_stride_bytes too small for T frames", fn);
+  if (out_dtype < 0 || out_dtype > 2) return fail(TG_ERR_INVALID, "%s: out_dtype must be 0 (f32), 1 (f16) or 2 (bf16)", fn);
+  if (B == 0) return TG_OK;
+  if (!ring || !actions || !out || !done) return fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  if (reinterpret_cast<uintptr_t>(out) & 15) return fail(TG_ERR_INVALID, "%s: out must be 16-byte aligned", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nxt = head_slot + 1 < T ? head_slot + 1 : 0;
+  const bool fused = S == 4 && (reinterpret_cast<uintptr_t>(ring) & 3) == 0 && frame_stride_bytes % 4 == 0 &&
+                     game_stride_bytes % 4 == 0 && aligned4(actions) && static_cast<unsigned>(shift + 127) <= 254u;
+  if (fused) {
+    tg::StepEmitArgs a{ring, actions, out, scalars, done, overflow, B, frame_stride_bytes, game_stride_bytes, T, head_slot, shift, t_step};
+    const int64_t blocks = (B * 4 + tg::kBlock - 1) / tg::kBlock;
+    if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
+    const bool nt = B * T * 64 * (out_dtype ? 2 : 4) >= tg::kStreamOutBytes || TG_SWITCH("TG_EMIT_NT");
+    const dim3 grid(static_cast<unsigned>(blocks)), block(tg::kBlock);
+    (void)hipGetLastError();
+#define TG_SE(OutT_)                                                                              \
+  do {                                                                                            \
+    if (nt) hipLaunchKernelGGL((tg::s4_step_emit_kernel<OutT_, true>), grid, block, 0, st, a);   \
+    else hipLaunchKernelGGL((tg::s4_step_emit_kernel<OutT_, false>), grid, block, 0, st, a);     \
+  } while (0)
+    if (out_dtype == 1) TG_SE(__half);
+    else if (out_dtype == 2) TG_SE(__hip_bfloat16);
+    else TG_SE(float);
+#undef TG_SE
+    return check_launch(fn);
+  }
+  // other sizes and layouts: the step into the next ring slot, then the frames (two launches inside this call)
+  if (int rc = tg_step_i8(ring + head_slot * frame_stride_bytes, ring + nxt * frame_stride_bytes, actions, done, overflow, B, S,
+                          game_stride_bytes, shift, stream))
+    return rc;
+  return tg_emit_frames(ring, out, scalars, out_dtype, B, S, T, nxt, t_step, frame_stride_bytes, game_stride_bytes, stream);
 }
 
 int tg_gen_from_factors_i8(const int8_t* actions, int8_t* target_out, uint8_t* overflow, int64_t B,

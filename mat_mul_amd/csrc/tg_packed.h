@@ -202,7 +202,7 @@ constexpr int packed_lds_bytes(int at) {
 template <int S, int TS, int MODE, bool NTS = false>
 __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, int at) {
   using G = PGeo<S, TS>;
-  constexpr bool SUB = (MODE != GENF);  // STEP, STEPS, MANY, EXPAND subtract
+  constexpr bool SUB = (MODE != GENF);  // STEP, MANY, EXPAND subtract
   extern __shared__ __attribute__((aligned(16))) short lds[];
   const int raw_stride = (at * 3 * S + 8 + 3) & ~3;  // bytes of raw tokens per team
   int8_t* const raw_all = reinterpret_cast<int8_t*>(lds + G::GPB * at * G::FSTRIDE);
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
 #pragma unroll
   for (int n = 0; n < G::NCH; ++n) {
     par[n] = uint4{0, 0, 0, 0};
-    if (MODE != GENF && MODE != STEPS && cv[n])  // STEPS loads only the chunks the action touches
+    if (MODE != GENF && cv[n])
       par[n] = load_chunk<G::TAIL>(a.in + g * a.in_stride + 16 * (lt + G::TSA * n), ctail[n]);
   }
 
@@ -400,65 +400,6 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
     }
     if (lt == 0 && live) {
       a.done[g] = any_nz ? 0 : 1;
-      if (a.overflow && any_ovf) a.overflow[g] = 1;
-    }
-  } else if constexpr (MODE == STEPS) {
-    // In-place step with the game's non-zero count carried in a.done_step (int32, in/out): a chunk
-    // whose rows all have u_i v_j = 0 (or whose weights are zero there) is neither loaded nor stored,
-    // and done = (nnz + sum over the touched chunks of (non-zeros after - before)) == 0.
-    stage(0, 1, true);
-    uint32_t ws[G::NSEG][8], wnz[G::NSEG];
-    window(F, ws);
-#pragma unroll
-    for (int s = 0; s < G::NSEG; ++s) {
-      wnz[s] = 0;
-#pragma unroll
-      for (int p = 0; p < 8; ++p) wnz[s] |= ws[s][p];
-    }
-    int delta = 0;
-#pragma unroll
-    for (int n = 0; n < G::NCH; ++n) {
-      uint32_t prs[G::NSEG];
-      bool touched = false;
-#pragma unroll
-      for (int s = 0; s < G::NSEG; ++s) {
-        const int uv = mul24_pinned(F[rowidx[n][s] & 0xffff], F[rowidx[n][s] >> 16]);
-        prs[s] = __builtin_amdgcn_perm(static_cast<uint32_t>(uv), static_cast<uint32_t>(uv), 0x05040100u);
-        touched |= (uv != 0) && (wnz[s] != 0);
-      }
-      if (cv[n] && touched) {
-        const int64_t off = g * a.in_stride + 16 * (lt + G::TSA * n);
-        const uint4 q0 = load_chunk<G::TAIL>(a.in + off, ctail[n]);
-        uint32_t A[8];
-        unpack_pairs(q0, A);
-#pragma unroll
-        for (int s = 0; s < G::NSEG; ++s)
-#pragma unroll
-          for (int p = 0; p < 8; ++p) A[p] = pk_mad_i16(prs[s], ws[s][p], A[p]);
-        uint32_t nzd = 0;
-        const uint4 q1 = pack_pairs(A, nzd, ovf);
-        delta += count_nonzero_bytes(q1) - count_nonzero_bytes(q0);
-        if (live) store_chunk<G::TAIL>(a.out + off, q1, ctail[n]);
-      }
-    }
-    bool any_ovf;
-    if constexpr (TS == 256) {
-      int* total = reinterpret_cast<int*>(flags);
-      __syncthreads();
-      if (tid == 0) *total = 0;
-      __syncthreads();
-      if (delta) atomicAdd(total, delta);
-      any_ovf = __syncthreads_or((ovf & 0xFF00FF00u) != 0);
-      delta = *total;
-    } else {
-#pragma unroll
-      for (int o = TS >> 1; o > 0; o >>= 1) delta += __shfl_xor(delta, o);
-      any_ovf = team_any<TS>((ovf & 0xFF00FF00u) != 0);
-    }
-    if (lt == 0 && live) {
-      const int nn = a.done_step[g] + delta;
-      a.done_step[g] = nn;
-      a.done[g] = nn == 0;
       if (a.overflow && any_ovf) a.overflow[g] = 1;
     }
   } else if constexpr (MODE == MANY || MODE == GENF) {

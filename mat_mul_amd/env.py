@@ -26,8 +26,7 @@ class TensorGameEnv:
     """
 
     def __init__(self, batch_size: int, dim_3d: int, device="cuda", shift: int = 1,
-                 track_overflow: bool = True, game_id_offset: int = 0, dim_t: int = 1,
-                 incremental: bool = False):
+                 track_overflow: bool = True, game_id_offset: int = 0, dim_t: int = 1):
         self.B, self.S, self.shift = int(batch_size), int(dim_3d), int(shift)
         self.T = int(dim_t)  # history depth (reference --dim_t, training.py:75); 1 = head only
         self.device = torch.device(device)
@@ -38,16 +37,6 @@ class TensorGameEnv:
         # slot, so the reference's history shift (act.py:271-274) is a pointer bump, not a copy
         self.ring = ops.alloc_ring(self.B, self.S, self.T, self.device)
         self.head = 0
-        # incremental=True (dim_t == 1 only): the env carries every game's non-zero count, and a step then
-        # touches only the chunks its action changes (tg_step_sparse_i8) instead of the whole state
-        self.incremental = bool(incremental) and self.T == 1
-        if self.incremental:
-            from . import _lib
-            if not _lib.AB_VARIANT:
-                raise TensorGameError("TensorGameEnv", -2, "incremental=True needs tg_step_sparse_i8, which exists only in "
-                                      "the A/B library (TG_LIB_VARIANT=ab); it is slower than the default step")
-        self._nnz = torch.zeros((self.B,), dtype=torch.int32, device=self.device) if self.incremental else None
-        self._nnz_valid = False
         self.done = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
         self.overflow = torch.zeros((self.B,), dtype=torch.uint8, device=self.device) if track_overflow else None
         self.t = 0
@@ -93,7 +82,6 @@ class TensorGameEnv:
         if self.overflow is not None:
             self.overflow.zero_()
         self.t = 0
-        self._nnz_valid = False
         return self.state
 
     # -- step -------------------------------------------------------------------------------
@@ -102,13 +90,6 @@ class TensorGameEnv:
         converted with a range check).  Returns (state, done)."""
         if actions.dtype != torch.int8:
             actions = ops.as_tokens(actions, self.device)
-        if self.incremental:
-            if not self._nnz_valid:  # after reset() / step_many(): recount once
-                self._nnz.copy_(ops.done(self.state, want_nnz=True)[1])
-                self._nnz_valid = True
-            ops.step_sparse(self.state, actions, self._nnz, done=self.done, overflow=self.overflow, shift=self.shift)
-            self.t += 1
-            return self.state, self.done
         nxt = (self.head + 1) % self.T
         ops.step(self.ring[:, self.head], actions, out=self.ring[:, nxt], done=self.done, overflow=self.overflow,
                  shift=self.shift)
@@ -116,13 +97,22 @@ class TensorGameEnv:
         self.t += 1
         return self.state, self.done
 
+    def step_observe(self, actions: torch.Tensor, dtype=torch.float32, out=None, scalars=None):
+        """``step()`` and ``model_input()`` of the new state in one call (one kernel at S=4): what the tree search does
+        between two network evaluations (act.py:178-183).  Returns (model_state (B,T,S,S,S), scalars (B,1), done)."""
+        if actions.dtype != torch.int8:
+            actions = ops.as_tokens(actions, self.device)
+        x, sc, _, nxt = ops.step_emit(self.ring, self.head, actions, float(self.t + 1), dtype=dtype, out=out, scalars=scalars,
+                                      done=self.done, overflow=self.overflow, shift=self.shift)
+        self.head = nxt
+        self.t += 1
+        return x, sc, self.done
+
     def graph_stepper(self, actions: torch.Tensor):
         """``step()`` bound to a STATIC token buffer and replayed as a hipGraph: returns a callable that applies
         whatever tokens ``actions`` (int8 (B,3S) on this device; refill it in place between calls) holds at that
         moment.  A replay costs the launch boundary (about 2.5 us at S=4, B=65 536) instead of the ~10 us of Python
         and ctypes in ``step()``; one graph per history slot is captured on first use."""
-        if self.incremental:
-            raise TensorGameError("graph_stepper", -1, "not available for incremental envs")
         if actions.dtype != torch.int8 or tuple(actions.shape) != (self.B, 3 * self.S) or actions.device != self.device \
                 or not actions.is_contiguous():
             raise TensorGameError("graph_stepper", -1, f"actions must be contiguous int8 {(self.B, 3 * self.S)} on {self.device}")
@@ -156,15 +146,14 @@ class TensorGameEnv:
         if self.T > 1:
             raise TensorGameError("step_many", -1, "step_many keeps no history; use step() when dim_t > 1")
         _, done_step = ops.step_many(self.state, actions, out=self.state, overflow=self.overflow, shift=self.shift)
-        self._nnz_valid = False
         self.t += actions.shape[1]
         return self.state, done_step
 
-    def expand(self, actions: torch.Tensor):
-        """k candidate children per game (the env is not advanced).  Returns (children, done, changed)."""
+    def expand(self, actions: torch.Tensor, want_keys: bool = False):
+        """k candidate children per game (the env is not advanced).  Returns (children, done, changed[, keys])."""
         if actions.dtype != torch.int8:
             actions = ops.as_tokens(actions, self.device)
-        return ops.expand(self.state, actions, shift=self.shift)
+        return ops.expand(self.state, actions, shift=self.shift, want_keys=want_keys)
 
     def snapshot(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """A copy of the current head states (the reference's step is functional: callers such as the tree search
@@ -184,8 +173,6 @@ class TensorGameEnv:
         return -ops.slice_rank(self.state)
 
     def nnz(self) -> torch.Tensor:
-        if self.incremental and self._nnz_valid:
-            return self._nnz
         return ops.done(self.state, want_nnz=True)[1]
 
     def any_overflow(self) -> bool:

@@ -69,6 +69,28 @@ def remove_null_actions(state: torch.Tensor, candidate_states: Sequence[torch.Te
     return [i for i, c in enumerate(candidate_states) if bool((_as_state(c)[:, 0] != head).any())]
 
 
+def state_to_key(state: torch.Tensor) -> torch.Tensor:
+    """The dict key of the search tree: reference utils.py:164-169 ``state_to_str(get_head_state(state))`` builds a
+    127-character string per state; here a 64-bit key per game (int64 bits), equal exactly when the head frames are
+    equal (up to 2^-64 collisions).  state (B,T,S,S,S) or (B,S,S,S)."""
+    s = _as_state(state)
+    head = s[:, 0] if s.dim() == 5 else s
+    S = head.shape[-1]
+    return ops.state_hash(head if head.stride()[1:] == (S * S, S, 1) else head.contiguous())
+
+
+def expand_new_candidates(state: torch.Tensor, actions: torch.Tensor, tree, shift: int = 1):
+    """The candidate filter at a leaf of reference ``extend_tree`` (act.py:183-195) for a BATCH of leaves: children =
+    ``get_child_states`` (:183), drop null actions (``remove_null_actions``, :185), drop children whose key is already
+    in the tree (``c not in new_mc_tree``, :188-195).  ``tree`` is a ``TranspositionTable``.  state (B,T,S,S,S) or
+    (B,S,S,S) int8, actions (B,k,3S).  Returns (children int8 (B,k,S,S,S), keep uint8 (B,k), keys int64 (B,k),
+    done uint8 (B,k)); the caller records an expanded leaf with ``tree.insert(state_to_key(state))`` (act.py:209-211)."""
+    s = _as_state(state)
+    head = (s[:, 0] if s.dim() == 5 else s).contiguous()
+    kids, done, changed, keys = ops.expand(head, ops.as_tokens(actions, head.device), shift=shift, want_keys=True)
+    return kids, tree.fresh(keys, mask=changed), keys, done
+
+
 def take_actions(action_seq, target_tensor: torch.Tensor, shift: int = 1) -> torch.Tensor:
     """reference datasets.py:144-153 (_take_actions): target (S,S,S) minus every action of the list."""
     target = _as_state(target_tensor)

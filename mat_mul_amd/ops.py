@@ -17,9 +17,9 @@ from . import _lib
 from ._lib import TG_MAX_ACTIONS, TG_MAX_S, TG_MAX_VALUES, TensorGameError, call
 
 __all__ = [
-    "step", "step_sparse", "copy_states", "prepare_step", "step_many", "step_stream", "step_stream_layout", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
+    "step", "copy_states", "prepare_step", "step_many", "step_stream", "step_stream_layout", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
     "gen_demos", "sample_basis", "change_basis", "as_tokens", "categorical_thresholds",
-    "alloc_states", "alloc_ring", "emit_frames", "state_hash", "slice_rank", "alloc_seen_table", "seen",
+    "alloc_states", "alloc_ring", "emit_frames", "step_emit", "state_hash", "slice_rank", "alloc_seen_table", "seen",
 ]
 
 
@@ -117,30 +117,6 @@ def step(state, actions, out=None, done=None, overflow=None, shift: int = 1):
     return out, done
 
 
-def step_sparse(state, actions, nnz, done=None, overflow=None, shift: int = 1):
-    """The in-place step for a caller that carries the per-game non-zero count: ``nnz`` (int32 (B,),
-    exact on entry, updated in place) lets the kernel skip loading and storing every chunk the action
-    does not touch.  Same results as ``step(state, actions, out=state)``; done[b] = (nnz[b] == 0).
-    Returns (state, done)."""
-    if not _lib.AB_VARIANT:
-        raise TensorGameError("step_sparse", -2, "tg_step_sparse_i8 exists only in the A/B library "
-                              "(set TG_LIB_VARIANT=ab before importing mat_mul_amd); it is slower than step()")
-    B, S, stride = _state_layout(state, "state")
-    dev = state.device
-    actions = _tokens(actions, (B,), S, dev, "actions")
-    nnz = _flag(nnz, (B,), torch.int32, dev, "nnz")
-    if nnz is None:
-        raise TensorGameError("step_sparse", -1, "nnz (int32 (B,)) is required; ops.done(state, want_nnz=True) computes it")
-    if done is None:
-        done = torch.empty((B,), dtype=torch.uint8, device=dev)
-    done = _flag(done, (B,), torch.uint8, dev, "done")
-    overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
-    with torch.cuda.device(dev):
-        call("tg_step_sparse_i8", _ptr(state), _ptr(actions), _ptr(nnz), _ptr(done), _ptr(overflow),
-             B, S, stride, int(shift), _stream(dev))
-    return state, done
-
-
 def copy_states(state, out=None):
     """out[b] = state[b] (a snapshot of a batch of games; the reference's step is functional and its callers
     keep the parent, act.py:183-195).  ``out`` may have a different game stride.  Returns out."""
@@ -230,7 +206,9 @@ def step_stream(state, actions, done=None, overflow=None, ready=None, progress=N
     overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
     for name, t, n in (("ready", ready, K), ("progress", progress, None), ("status", status, 1)):
         if t is not None and (t.dtype not in (torch.int32, torch.uint32) or t.dim() != 1 or not t.is_contiguous()
-                              or (n is not None and t.numel() != n) or (t.device != dev and not t.is_pinned())):
+                              or (n is not None and t.numel() != n) or t.device != dev):
+            # (device memory only: the stepper polls and publishes with agent-scope accesses; a host producer
+            # releases a step by a fill / copy enqueued on another stream, not by writing mapped memory)
             raise TensorGameError("step_stream", -1, f"{name} must be a contiguous 32-bit vector on {dev}")
     if progress is not None and progress.numel() < step_stream_layout(B, S, dev)[0]:
         raise TensorGameError("step_stream", -1, "progress needs one word per unit (ops.step_stream_layout)")
@@ -470,6 +448,42 @@ def emit_frames(ring, head_slot: int, t_step: float = 0.0, dtype=torch.float32, 
         call("tg_emit_frames", _ptr(ring), _ptr(out), _ptr(scalars), codes[dtype], B, S, T,
              int(head_slot) % T, C.c_float(float(t_step)), fs, gs, _stream(dev))
     return out, scalars
+
+
+def step_emit(ring, head_slot: int, actions, t_step: float = 0.0, dtype=torch.float32, out=None, scalars=None, done=None,
+              overflow=None, shift: int = 1):
+    """One env step on the history ring and the model input of the new state, in one call (the fused form of
+    ``step`` + ``emit_frames``; one kernel at S=4).  The new head is written into slot ``(head_slot + 1) % T``.
+    Returns (out (B,T,S,S,S), scalars (B,1), done (B,), new_head_slot)."""
+    _need_gpu(ring, "ring")
+    if ring.dtype != torch.int8 or ring.dim() != 5 or not (ring.shape[2] == ring.shape[3] == ring.shape[4]):
+        raise TensorGameError("step_emit", -1, f"ring must be int8 (B,T,S,S,S), got {ring.dtype} {tuple(ring.shape)}")
+    B, T, S = ring.shape[0], ring.shape[1], ring.shape[2]
+    if ring.stride()[2:] != (S * S, S, 1):
+        raise TensorGameError("step_emit", -1, "each frame must be C-contiguous (S,S,S)")
+    fs = ring.stride(1) if T > 1 else S ** 3
+    gs = ring.stride(0) if B > 1 else max(ring.stride(0), (T - 1) * fs + S ** 3)
+    codes = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+    if dtype not in codes:
+        raise TensorGameError("step_emit", -1, "dtype must be float32, float16 or bfloat16")
+    dev = ring.device
+    actions = _tokens(actions, (B,), S, dev, "actions")
+    if out is None:
+        out = torch.empty((B, T, S, S, S), dtype=dtype, device=dev)
+    if out.dtype != dtype or tuple(out.shape) != (B, T, S, S, S) or not out.is_contiguous() or out.device != dev:
+        raise TensorGameError("step_emit", -1, "out must be contiguous (B,T,S,S,S) of the requested dtype")
+    if scalars is None:
+        scalars = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    scalars = _flag(scalars, (B, 1), torch.float32, dev, "scalars")
+    if done is None:
+        done = torch.empty((B,), dtype=torch.uint8, device=dev)
+    done = _flag(done, (B,), torch.uint8, dev, "done")
+    overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
+    head = int(head_slot) % T
+    with torch.cuda.device(dev):
+        call("tg_step_emit", _ptr(ring), _ptr(actions), _ptr(out), _ptr(scalars), _ptr(done), _ptr(overflow), codes[dtype],
+             B, S, T, head, C.c_float(float(t_step)), fs, gs, int(shift), _stream(dev))
+    return out, scalars, done, (head + 1) % T
 
 
 def state_hash(state) -> torch.Tensor:

@@ -19,7 +19,7 @@ import statistics
 import sys
 from pathlib import Path
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = Path(__file__).resolve().parent.parent
 src = root / "gpurun_out" / f"prof_{tag}"
 dst = root / "profiles"
@@ -62,6 +62,8 @@ for name in ("bench_driver", "bench_graph", "bench_graph_S16", "bench_eager", "b
 lf = src / "launch_floor.txt"
 if lf.exists():
     shutil.copy(lf, dst / f"{tag}_launch_floor.txt")
+if (src / "share_floor.txt").exists():
+    shutil.copy(src / "share_floor.txt", dst / f"{tag}_share_floor.txt")
 for probe, name in (("read_bw_probe", "read_bandwidth"), ("issue_rate_probe", "issue_rates"), ("shader_clock_probe", "shader_clock"),
                     ("expand_probe", "expand_probe"), ("aux_ops", "aux_ops")):
     if (src / f"{probe}.txt").exists():
@@ -78,7 +80,8 @@ for d in sorted(glob.glob(str(src / "pmc_*_SIZE"))):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         # the STEP kernels: s4_kernel<0>, packed_kernel<S, TS, 0>, s16_step_kernel<0, LINES>, s25_step_kernel, s9_step_kernel
-        if "tg::" in n and ("<0>" in n or ", 0>" in n or "<0, " in n or "s25_step_kernel" in n or "s9_step_kernel" in n) and "copy" not in n:
+        if "tg::" in n and ("<0>" in n or ", 0>" in n or "<0, " in n or "s25_step_kernel" in n or "s9_step_kernel" in n
+                            or "s4_step_kernel" in n) and "copy" not in n and "step_emit" not in n:
             vals[n].append(float(r["Counter_Value"]))
             durs[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for n, v in vals.items():

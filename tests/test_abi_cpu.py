@@ -22,20 +22,18 @@ def declared_symbols(ab=False):
 
 def test_header_symbols_all_exported():
     syms = declared_symbols()
-    assert len(syms) == 22
+    assert len(syms) == 23
     assert sorted(_lib.SIGNATURES) == syms                 # the ctypes table covers the header exactly
     lib = C.CDLL(str(_lib.LIB_PATH))
     for s in syms:
         assert hasattr(lib, s), s
     assert lib.tg_abi_version() == 2
-    # the A/B variant exports the same entries plus the measurement-only one
+    # the A/B variant exports exactly the same entries (it differs only by its environment switches)
     from mat_mul_amd import build
-    extra = sorted(set(declared_symbols(ab=True)) - set(syms))
-    assert extra == ["tg_step_sparse_i8"]
+    assert declared_symbols(ab=True) == syms
     ab = C.CDLL(str(build.lib_path(ab=True)))
-    for s in syms + extra:
+    for s in syms:
         assert hasattr(ab, s), s
-    assert not hasattr(lib, "tg_step_sparse_i8")
 
 
 def test_argument_validation_without_gpu():

@@ -1,6 +1,5 @@
-"""The A/B library (libtensorgame_ab.so, -DTG_AB_SWITCHES) on the GPU: the measurement switches, the
-first-generation 32-bit kernels and tg_step_sparse_i8 are not part of the product library, but whatever they
-compute must stay bit-exact too.  Every case runs in a child process with TG_LIB_VARIANT=ab, because a process
+"""The A/B library (libtensorgame_ab.so, -DTG_AB_SWITCHES) on the GPU: the measurement switches force kernel variants
+the product dispatch takes only at other sizes (or no longer takes); whatever they compute must stay bit-exact too.  Every case runs in a child process with TG_LIB_VARIANT=ab, because a process
 binds ONE variant of the library when mat_mul_amd is first imported."""
 import os
 import subprocess
@@ -44,55 +43,6 @@ for S, B, K in [(9, 9, 6), (16, 6, 5), (25, 3, 7)]:
 print("AB_OK")
 '''
 
-SPARSE_SCRIPT = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from mat_mul_amd import TensorGameEnv, ops, _lib
-from oracle import tensor_game as O
-assert _lib.AB_VARIANT
-DEV = "cuda:0"
-dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
-host = lambda t: t.detach().cpu().numpy()
-def padded(st):
-    t = ops.alloc_states(st.shape[0], st.shape[1], DEV); t.copy_(torch.from_numpy(np.ascontiguousarray(st))); return t
-for S, B in [(4, 70), (9, 33), (16, 12), (25, 5), (6, 9), (16, 1)]:
-    rng = np.random.default_rng(S * 11 + B)
-    K = 9
-    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, K, 3 * S)).astype(np.int8)
-    ac[:, 3] = rng.integers(0, 3, size=(B, 3 * S))                       # a dense action
-    ac[1::3, 5] = rng.integers(-3, 6, size=ac[1::3, 5].shape)            # wide factors
-    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
-    st[::4] = O.gen_from_factors_i8(ac[::4, :4])[0]                      # these reach zero after step 3
-    st[2::5] = rng.choice([-128, 127, 0], size=st[2::5].shape)           # these overflow
-    for layout in ("padded", "packed"):
-        t = padded(st) if layout == "padded" else dev(st)
-        nnz = ops.done(t, want_nnz=True)[1]
-        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
-        cur, want_ovf = st.copy(), np.zeros(B, np.uint8)
-        for k in range(K):
-            cur, want_done, o = O.step_i8(cur, ac[:, k])
-            want_ovf |= o
-            out, done = ops.step_sparse(t, dev(ac[:, k]), nnz, overflow=ovf)
-            assert out.data_ptr() == t.data_ptr()
-            assert np.array_equal(host(t), cur), (S, layout, k)
-            assert np.array_equal(host(done), want_done), (S, layout, k)
-            assert np.array_equal(host(nnz), O.nnz_per_game(cur)), (S, layout, k)
-            assert np.array_equal(host(ovf), want_ovf), (S, layout, k)
-        assert want_ovf.any() or B == 1
-    env = TensorGameEnv(B, S, DEV, incremental=True)
-    env.reset(dev(st))
-    cur = st.copy()
-    for k in range(4):
-        cur, want_done, _ = O.step_i8(cur, ac[:, k])
-        state, done = env.step(dev(ac[:, k]))
-        assert np.array_equal(host(state), cur) and np.array_equal(host(done), want_done)
-        assert np.array_equal(host(env.nnz()), O.nnz_per_game(cur))
-    idx = [b for b in range(0, B, 4) if b % 5 != 2]                       # terminating games not overwritten above
-    assert host(env.done)[idx].all()
-print("SPARSE_OK")
-'''
-
-
 STEP_SCRIPT = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
@@ -104,7 +54,7 @@ dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 host = lambda t: t.detach().cpu().numpy()
 def padded(st):
     t = ops.alloc_states(st.shape[0], st.shape[1], DEV); t.copy_(torch.from_numpy(np.ascontiguousarray(st))); return t
-for S, B in [(16, 1), (16, 3), (16, 131), (25, 2), (25, 37), (9, 1), (9, 70)]:
+for S, B in [(16, 1), (16, 3), (16, 131), (25, 2), (25, 37), (9, 1), (9, 70), (4, 1), (4, 3), (4, 70), (4, 257)]:
     rng = np.random.default_rng(S * 7 + B)
     for case in ("sparse", "dense", "wide", "overflow", "null"):
         st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
@@ -139,26 +89,72 @@ def _run(script_text, tmp_path, marker, extra_env=None):
     assert res.returncode == 0 and marker in res.stdout, (res.stdout[-1000:], res.stderr[-3000:])
 
 
-@pytest.mark.parametrize("env_name", ["TG_FORCE_I32", "TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA", "TG_MFMA_MANY_ALWAYS", "TG_NO_FUSED_GEN"])
+@pytest.mark.parametrize("env_name", ["TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA", "TG_MFMA_MANY_ALWAYS", "TG_NO_FUSED_GEN"])
 def test_ab_switch_paths_stay_exact(env_name, tmp_path):
-    """The measurement switches (32-bit cursor kernels; packed chunks instead of rows; vector ALU instead of
-    the matrix cores) select kernels that the product dispatch no longer uses -- they must stay bit-exact."""
+    """The measurement switches (packed chunks instead of rows; vector ALU instead of the matrix cores) select
+    kernels that the product dispatch no longer uses at these shapes -- they must stay bit-exact."""
     _run(AB_SCRIPT, tmp_path, "AB_OK", {env_name: "1"})
 
 
-@pytest.mark.parametrize("env_name", ["TG_S16_LINES", "TG_S16_NT_LOADS", "TG_S25_LINES", "TG_S25_NT_LOADS", "TG_NO_S25_DIRECT", "TG_NO_S16_DIRECT",
-                                      "TG_NO_S9_DIRECT"])
-def test_single_step_variants_stay_exact(env_name, tmp_path):
-    """The S=16 / S=25 steps with whole-line stores (the product takes them from 96 MiB of states on; forced here at small
-    batches) and with non-temporal state loads on top (from 320 MiB on), and the staged kernels that the direct S=9 / S=16 / S=25 step kernels replaced: sparse, dense (more candidate
-    rows than the queue holds), wide-factor, overflowing and null actions, in place and out of place."""
-    _run(STEP_SCRIPT, tmp_path, "STEP_OK", {env_name: "1"})
+@pytest.mark.parametrize("env_names", ["TG_S16_LINES", "TG_S16_NT_LOADS", "TG_S25_LINES", "TG_S25_NT_LOADS", "TG_NO_S25_DIRECT",
+                                       "TG_NO_S16_DIRECT", "TG_NO_S9_DIRECT", "TG_S4_NT_LOADS", "TG_S4_NT_LOADS TG_S4_TOKEN_WAIT"])
+def test_single_step_variants_stay_exact(env_names, tmp_path):
+    """The step variants the product takes by footprint only, forced here at small batches: S=16 / S=25 with whole-line
+    stores (from 96 MiB of states on) and non-temporal state loads on top (320 MiB .. 1.5 GiB), S=4 with non-temporal
+    loads (from 96 MiB on) and with the token awaited first (from 1 GiB on), and the staged kernels that the direct
+    S=9 / S=16 / S=25 step kernels replaced: sparse, dense (more candidate rows than the queue holds), wide-factor,
+    overflowing and null actions, in place and out of place."""
+    _run(STEP_SCRIPT, tmp_path, "STEP_OK", {n: "1" for n in env_names.split()})
 
 
-def test_step_sparse_rollout_matches_dense(tmp_path):
-    """tg_step_sparse_i8 (A/B library only) over multi-step rollouts: state, done and the carried nnz equal the
-    oracle at every step -- sparse, dense and wide-factor actions, games that terminate, games that overflow."""
-    _run(SPARSE_SCRIPT, tmp_path, "SPARSE_OK")
+STREAM_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from mat_mul_amd import ops, _lib
+from oracle import tensor_game as O
+assert _lib.AB_VARIANT
+DEV = "cuda:0"
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+host = lambda t: t.detach().cpu().numpy()
+def padded(st):
+    t = ops.alloc_states(st.shape[0], st.shape[1], DEV); t.copy_(torch.from_numpy(np.ascontiguousarray(st))); return t
+rng = np.random.default_rng(23)
+for S, B, k in [(4, 70, 8), (4, 5, 3), (16, 9, 4), (9, 19, 5), (25, 3, 3)]:
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, k, 3 * S)).astype(np.int8)
+    ac[::3, 0] = rng.integers(-40, 40, size=ac[::3, 0].shape)                       # wide factors -> 32-bit redo
+    kids_o, done_o, chg_o, ovf_o = O.expand_i8(st, ac)
+    ovf = torch.zeros((B, k), dtype=torch.uint8, device=DEV)
+    kids, done, chg, keys = ops.expand(padded(st), dev(ac), overflow=ovf, want_keys=True)
+    assert np.array_equal(host(kids), kids_o) and np.array_equal(host(done), done_o), (S, B, k)
+    assert np.array_equal(host(chg), chg_o) and np.array_equal(host(ovf), ovf_o), (S, B, k)
+    assert np.array_equal(host(keys).view(np.uint64), O.state_hash(kids_o.reshape(B * k, S, S, S)).reshape(B, k))
+    # copy: same and different strides, guard bytes behind every game untouched
+    src = padded(st)
+    wide = torch.full((B, S ** 3 + 48), 77, dtype=torch.int8, device=DEV)
+    dst = wide[:, :S ** 3].unflatten(1, (S, S, S))
+    ops.copy_states(src, dst)
+    assert np.array_equal(host(dst), st) and bool((wide[:, S ** 3:] == 77).all())
+    assert np.array_equal(host(ops.copy_states(src)), st)
+    # model-input frames
+    T = 3
+    ring = ops.alloc_ring(B, S, T, DEV)
+    frames = rng.integers(-128, 128, size=(B, T, S, S, S)).astype(np.int8)
+    ring.copy_(dev(frames))
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        x, sc = ops.emit_frames(ring, 1, 4.0, dt)
+        want = frames[:, [1, 0, 2]].astype(np.float32)                               # newest first from head slot 1
+        assert np.array_equal(x.float().cpu().numpy(), want) and bool((sc == 4.0).all()), (S, dt)
+print("STREAM_OK")
+'''
+
+
+@pytest.mark.parametrize("env_name", ["TG_EXPAND_NT", "TG_EXPAND_NO_NT", "TG_COPY_NT1", "TG_COPY_NT2", "TG_COPY_PLAIN", "TG_EMIT_NT"])
+def test_write_stream_variants_stay_exact(env_name, tmp_path):
+    """The non-temporal forms of the write streams -- expand's children (from 128 MiB of children on), the copy's loads and
+    stores (by footprint) and the model-input frames (from 128 MiB of output on) -- forced at small batches against the
+    oracle; the product reaches them only through full-size property tests."""
+    _run(STREAM_SCRIPT, tmp_path, "STREAM_OK", {env_name: "1"})
 
 
 def test_product_library_has_no_switches():
@@ -169,7 +165,6 @@ def test_product_library_has_no_switches():
 
     assert not _lib.AB_VARIANT
     lib = C.CDLL(str(build.LIB_PATH))
-    assert not hasattr(lib, "tg_step_sparse_i8")
     nm = subprocess.run(["nm", "-D", "--undefined-only", str(build.LIB_PATH)], capture_output=True, text=True)
     if nm.returncode == 0:
         assert "getenv" not in nm.stdout

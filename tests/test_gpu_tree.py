@@ -31,7 +31,7 @@ def padded(states_np):
 
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("name", TREE_CASES)
-def test_tree_filter_matches_reference_extend_tree(name, fused):
+def test_tree_filter_matches_reference_extend_tree(name, fused):  # noqa: C901
     """Every expansion attempt the reference made, replayed through the C ABI: the survivors must be the reference's
     `not_dupl_actions`, in order, and attempts the reference had to repeat must leave no survivor."""
     tt = TranspositionTable(1 << 12, DEV)
@@ -108,3 +108,83 @@ def test_expand_keys_match_state_hash():
             assert np.array_equal(host(keys).view(np.uint64), want), (S, B, k)
             kids_o, done_o, changed_o, _ = O.expand_i8(st, ac)
             assert np.array_equal(host(kids), kids_o) and np.array_equal(host(done), done_o)
+
+
+# ------------------------------------------------------------------ N1 fused: step + model input in one call
+@pytest.mark.parametrize("S,T", [(4, 3), (9, 2)])
+def test_step_emit_matches_reference_rollouts(golden, S, T):
+    """The 5-step get_child_states rollouts recorded from the reference (T-frame history, act.py:271-274): after every
+    fused step the emitted model input equals the reference's (B,T,S,S,S) state, in all three float types, and the ring
+    holds the same frames as step() + model_input() would."""
+    from mat_mul_amd import TensorGameEnv
+
+    g = golden("next_rows")
+    states, actions = g[f"hist_S{S}_T{T}_states"], g[f"hist_S{S}_T{T}_actions"]
+    B = states.shape[1]
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        env = TensorGameEnv(B, S, DEV, dim_t=T)
+        env.reset(dev(states[0][:, 0]))
+        ref = TensorGameEnv(B, S, DEV, dim_t=T)
+        ref.reset(dev(states[0][:, 0]))
+        for k in range(actions.shape[0]):
+            x, sc, done = env.step_observe(dev(actions[k]), dtype=dt)
+            assert x.dtype == dt and np.array_equal(x.float().cpu().numpy(), states[k + 1].astype(np.float32)), (S, T, k, dt)
+            assert bool((sc == k + 1).all())
+            ref.step(dev(actions[k]))
+            xr, scr = ref.model_input(dt)
+            assert torch.equal(x, xr) and torch.equal(sc, scr) and torch.equal(done, ref.done)
+            assert torch.equal(env.state, ref.state) and env.head == ref.head
+
+
+def test_step_emit_random_against_oracle():
+    rng = np.random.default_rng(41)
+    for S, B, T in [(4, 1, 1), (4, 3, 2), (4, 70, 4), (4, 257, 5), (4, 65, 1), (16, 9, 3), (25, 3, 2), (5, 4, 2)]:
+        frames = rng.integers(-3, 4, size=(B, T, S, S, S)).astype(np.int8)
+        ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)).astype(np.int8)
+        ac[::4] = rng.integers(-60, 60, size=ac[::4].shape)                   # wide factors: the 32-bit redo, overflow
+        for head in range(T):
+            ring = ops.alloc_ring(B, S, T, DEV)
+            ring.copy_(dev(frames))
+            ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+            x, sc, done, nxt = ops.step_emit(ring, head, dev(ac), 7.0, overflow=ovf)
+            new, want_done, want_ovf = O.step_i8(frames[:, head], ac)
+            want = frames.copy()
+            want[:, (head + 1) % T] = new
+            assert nxt == (head + 1) % T and np.array_equal(host(ring), want), (S, B, T, head)
+            order = [(nxt - f) % T for f in range(T)]
+            assert np.array_equal(host(x), want[:, order].astype(np.float32)), (S, B, T, head)
+            assert np.array_equal(host(done), want_done) and np.array_equal(host(ovf), want_ovf) and bool((sc == 7.0).all())
+    # shift 2 (StrassenDemoDataset tokens) and guard bytes around the output
+    B, S, T = 33, 4, 3
+    frames = rng.integers(-2, 3, size=(B, T, S, S, S)).astype(np.int8)
+    ac = rng.integers(1, 4, size=(B, 12)).astype(np.int8)
+    ring = ops.alloc_ring(B, S, T, DEV)
+    ring.copy_(dev(frames))
+    buf = torch.full((B * T * 64 + 64,), 99.0, dtype=torch.float16, device=DEV)
+    x = buf[32:32 + B * T * 64].view(B, T, S, S, S)
+    ops.step_emit(ring, 0, dev(ac), dtype=torch.float16, out=x, shift=2)
+    new, _, _ = O.step_i8(frames[:, 0], ac, shift=2)
+    assert np.array_equal(host(x[:, 0]).astype(np.int8), new) and bool((buf[:32] == 99).all()) and bool((buf[-32:] == 99).all())
+
+
+def test_functional_expand_new_candidates_batched():
+    """The reference-named wrapper over a BATCH of leaves against the oracle's per-leaf filter sharing one tree."""
+    from mat_mul_amd import functional as F
+
+    rng = np.random.default_rng(77)
+    B, S, k, T = 40, 4, 6, 2
+    pool = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(5, 3 * S)).astype(np.int8)
+    state = np.zeros((B, T, S, S, S), np.int8)
+    state[:, 0] = rng.integers(-1, 2, size=(B // 4, S, S, S)).astype(np.int8).repeat(4, axis=0)   # repeated leaves
+    acts = pool[rng.integers(0, 5, size=(B, k))]
+    tt = TranspositionTable(1 << 10, DEV)
+    table = set()
+    seeds = O.step_i8(state[:8, 0], acts[:8, 0])[0]                                # some children are already tree keys
+    tt.insert(ops.state_hash(padded(seeds)))
+    O.seen_u64(O.state_hash(seeds), table, insert=True)
+    kids, keep, keys, done = F.expand_new_candidates(dev(state), dev(acts), tt)
+    want = np.stack([O.tree_filter(state[b, 0], acts[b], table)[0] for b in range(B)])
+    assert np.array_equal(host(keep), want) and 0 < int(want.sum()) < want.size
+    assert np.array_equal(host(F.state_to_key(dev(state))).view(np.uint64), O.state_hash(state[:, 0]))
+    tt.insert(F.state_to_key(dev(state)))
+    assert tt.count() == len(table | set(int(x) for x in O.state_hash(state[:, 0])))

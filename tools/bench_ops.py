@@ -78,12 +78,6 @@ def main():
         a0 = tokens[:, 0].contiguous()
         t = timeit(lambda: ops.step(state, a0, out=state, done=done, overflow=overflow), iters=50)
         emit("step (in place)", S, B, t, nbytes=B * (2 * N + 3 * S + 1), units=B)
-        from mat_mul_amd import _lib
-        if _lib.AB_VARIANT:  # tg_step_sparse_i8 exists only in the A/B library (TG_LIB_VARIANT=ab)
-            nnz = ops.done(state, want_nnz=True)[1]
-            t = timeit(lambda: ops.step_sparse(state, a0, nnz, done=done, overflow=overflow), iters=50)
-            emit("step_sparse (in place, nnz carried)", S, B, t, nbytes=B * (2 * N + 3 * S + 1), units=B,
-                 note="GBps/hbm_frac price the DENSE algorithmic bytes; the kernel moves far fewer")
         # K fused steps
         state.copy_(target)
         ds = torch.zeros(B, dtype=torch.int32, device=DEV)

@@ -16,6 +16,7 @@ ap.add_argument("--S", type=int, default=25)
 ap.add_argument("--B", type=int, default=4096)
 ap.add_argument("--R", type=int, default=64)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--basis", action="store_true", help="--op gen: in a random GL(S,Z) basis")
 a = ap.parse_args()
 dev = "cuda:0"
 tokens, target = ops.gen_demos(a.B, a.S, a.R, dev, seed=1)
@@ -27,6 +28,7 @@ a0 = tokens[:, 0].contiguous()
 k = min(8, a.R)
 kids = ops.alloc_states(a.B * k, a.S, dev).unflatten(0, (a.B, k)) if a.op == "expand" else None
 ak = tokens[:, :k].contiguous()
+P = ops.sample_basis(a.B, a.S, dev, seed=11) if a.basis else None
 torch.cuda.synchronize()
 for _ in range(a.iters):
     if a.op == "genf":
@@ -38,6 +40,6 @@ for _ in range(a.iters):
     elif a.op == "expand":
         ops.expand(target, ak, out=kids)
     elif a.op == "gen":
-        ops.gen_demos(a.B, a.S, a.R, dev, seed=1, target=state, actions=tokens)
+        ops.gen_demos(a.B, a.S, a.R, dev, seed=1, target=state, actions=tokens, basis=P)
 torch.cuda.synchronize()
 print("ok")
