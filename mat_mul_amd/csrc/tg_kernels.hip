@@ -323,6 +323,54 @@ __device__ __forceinline__ uint4 s4_step_slice(const uint4 in_slice, uint32_t du
   return s4_step_unpacked(P, in_slice, du, dv, dw, q, shift, nz, ovf);
 }
 
+// Digit form of the same step (round 3, second half): a dword of the slice -- row j, elements l = 0..3 -- is read as ONE
+// base-256 integer whose digits are the biased bytes b_l = x_l + 128, and the game's w as the integer
+// W = sum_l w_l 256^l (= the token dword minus shift * 0x01010101: tokens below 128 make that exact).  The update of
+// the whole row is then linear in ONE 32-bit multiply-add,
+//     X'_j = X_j + v_j * G  (mod 2^32),   G = -u_i * W,
+// and X'_j is the packed result exactly when every digit b_l - u_i v_j w_l stays in [0, 255] (no carry or borrow
+// crosses a byte).  That is guaranteed up front, not checked afterwards: all twelve token bytes <= 3 and
+// 0 <= shift <= 3 bound every factor by F = max(shift, 3 - shift) <= 3, and the slice's L1 norm (four v_sad_u8 on the
+// biased dwords, which need no unpacking either) bounds every |x_l|; L1 <= 127 - F^3 keeps all results inside int8.
+// 3 VALU per dword (bias, v_mad_u64_u32, unbias) + 1 for the norm instead of 9 for unpack / two packed MADs / pack /
+// range: ~31 instead of ~51 on the data path.  Lanes outside the guarantee (tokens of a wider vocabulary, large
+// entries, other shifts) take s4_step_unpacked; results are identical wherever both apply (tests force each form).
+// pre: the part that needs the state only (runs while the token dword is still on its way)
+__device__ __forceinline__ uint32_t s4_digits_pre(const uint4& in_slice, uint32_t (&xb)[4]) {
+  const uint32_t x[4] = {in_slice.x, in_slice.y, in_slice.z, in_slice.w};
+  uint32_t l1 = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    xb[d] = x[d] ^ 0x80808080u;
+    l1 = __builtin_amdgcn_sad_u8(xb[d], 0x80808080u, l1);
+  }
+  return l1;
+}
+// wave-uniform: the largest slice norm the digit form accepts under this shift, -1 when it never applies
+__host__ __device__ __forceinline__ int s4_digits_limit(int shift) {
+  const int F = shift > 3 - shift ? shift : 3 - shift;
+  return static_cast<unsigned>(shift) <= 3u ? 127 - F * F * F : -1;
+}
+// returns false when this lane must take the packed form; nz |= result bytes
+__device__ __forceinline__ bool s4_step_digits(const uint32_t (&xb)[4], uint32_t l1, int limit, uint32_t du, uint32_t dv,
+                                               uint32_t dw, int q, int shift, uint4& out, uint32_t& nz) {
+  const uint32_t wide = (du | dv | dw) & 0xFCFCFCFCu;
+  // -(u_i): byte q of du comes down by v_alignbyte_b32 (shifts by q BYTES: no 8 * q), then one SDWA subtract
+  const uint32_t nui = static_cast<uint32_t>(shift) - (__builtin_amdgcn_alignbyte(du, du, static_cast<uint32_t>(q)) & 255u);
+  const uint32_t W = dw - static_cast<uint32_t>(shift) * 0x01010101u;
+  const uint32_t G = nui * W;
+  uint32_t o[4], vj[4];
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(vj[0]) : "v"(dv), "s"(shift));
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(vj[1]) : "v"(dv), "s"(shift));
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(vj[2]) : "v"(dv), "s"(shift));
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(vj[3]) : "v"(dv), "s"(shift));
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = (xb[d] + vj[d] * G) ^ 0x80808080u;
+  out = uint4{o[0], o[1], o[2], o[3]};
+  nz |= o[0] | o[1] | o[2] | o[3];
+  return wide == 0 && static_cast<int>(l1) <= limit;
+}
+
 // The game's 12 token bytes as three dwords (u | v | w) in every lane of its 4-lane team from ONE dword load per lane:
 // lane q loads dword min(q, 2) and the team exchanges them by DPP quad broadcasts (three v_mov_b32_dpp).  A
 // global_load_dwordx3 per lane asks the memory pipeline for 48 bytes per game where 12 are distinct; with the token
@@ -352,7 +400,7 @@ __device__ __forceinline__ void s4_team_tokens(const int8_t* blk_tok, int team, 
 //        wait halves the state requests a wavefront keeps in flight, and the HBM side serves the thinner stream better
 //        (2 GiB of states: 815 -> 793 us, 512 MiB: 202 -> 188; at 256 MiB the same wait costs 8 %).
 // =============================================================================================
-// Its own slim argument block (56 bytes: one scalar-load round trip) and 32-bit strides: with 8 wavefronts per SIMD
+// Its own slim argument block (64 bytes: two s_load_dwordx8, one scalar-load round trip) and 32-bit strides: with 8 wavefronts per SIMD
 // every instruction in front of the loads, and every VALU instruction behind them, is on the launch's critical path
 // (one VALU instruction per lane = 0.014 us of a 3.6 us launch at 131 072 games).
 struct S4StepArgs {
@@ -364,9 +412,12 @@ struct S4StepArgs {
   int64_t B;
   uint32_t stride;  // in == out stride (tg_step_i8 has one), < 2^20
   int shift;
+  int digits_limit;  // s4_digits_limit(shift), from the host (a branch in front of the loads' consumers costs a block)
 };
 
-template <bool NTL, bool TW>
+//   DIG: the digit form (s4_step_digits) first, the packed form for the lanes it does not cover; false only in the
+//        A/B library (TG_S4_NO_DIGITS), for tests and measurements of the packed form alone.
+template <bool NTL, bool TW, bool DIG = true>
 __global__ __launch_bounds__(kBlock) void s4_step_kernel(S4StepArgs a) {
   constexpr int GPB = kBlock / 4;  // 64 games per workgroup
   const int64_t g0 = static_cast<int64_t>(blockIdx.x) * GPB;
@@ -386,30 +437,63 @@ __global__ __launch_bounds__(kBlock) void s4_step_kernel(S4StepArgs a) {
       pk = *reinterpret_cast<const uint4*>(in_blk + off);
     }
   };
-  uint32_t P[8];
+  uint32_t P[8], xb[4], l1 = 0;
+  auto state_only = [&]() {  // what can be done before the token is there
+    if constexpr (DIG) l1 = s4_digits_pre(pk, xb);
+    else s4_unpack_biased(pk, P);
+  };
   if constexpr (TW) {  // token, wait, slice (the throttled order for batches far beyond the caches)
     s4_team_tokens(a.actions + g0 * 12, lg, q, du, dv, dw);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     load_state();
-    s4_unpack_biased(pk, P);
+    state_only();
   } else {
     // The slice FIRST, then the token dword: the states of an in-place rollout sit in L2 / the Infinity Cache, the
-    // step's token block comes from wherever its producer left it -- so the slice is unpacked (12 of the ~50 VALU
-    // operations) while the token is still on its way (vmcnt retires in order).
-    load_state();
-    const uint32_t mine = s4_team_token_load(a.actions + g0 * 12, lg, q);
-    s4_unpack_biased(pk, P);
-    __builtin_amdgcn_sched_barrier(0);
+    // step's token block comes from wherever its producer left it -- so the slice is biased and measured (or
+    // unpacked) while the token is still on its way (vmcnt retires in order).
+    // Both requests and both waits are written out: hipcc otherwise issues the token load BEHIND the wait for the slice
+    // (a sched_barrier does not hold it: the load is placed at instruction selection), which puts two memory round
+    // trips in series.  The "+v" operands of the waits tie the consumers of each register to its wait.
+    v4u_t sv;
+    uint32_t mine;
+    const int8_t* const tok_blk = a.actions + g0 * 12;
+    const uint32_t toff = __umul24(static_cast<uint32_t>(lg), 12u) + min(4u * static_cast<uint32_t>(q), 8u);
+    if constexpr (NTL) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(sv) : "v"(off), "s"(in_blk) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(sv) : "v"(off), "s"(in_blk) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" : "=&v"(mine) : "v"(toff), "s"(tok_blk) : "memory");
+    asm volatile("s_waitcnt vmcnt(1)" : "+v"(sv) : : "memory");
+    pk = uint4{sv.x, sv.y, sv.z, sv.w};
+    state_only();
+    if constexpr (DIG)  // (l1 / P as operands: the state-only work stays in front of this wait)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(mine), "+v"(l1) : : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(mine), "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(P[5]), "+v"(P[6]), "+v"(P[7]) : : "memory");
     s4_team_token_bcast(mine, du, dv, dw);
   }
   uint32_t nz = 0;
   int ovf = 0;
-  pk = s4_step_unpacked(P, pk, du, dv, dw, q, a.shift, nz, ovf);
+  if constexpr (DIG) {
+    uint4 o;
+    if (__builtin_expect(s4_step_digits(xb, l1, a.digits_limit, du, dv, dw, q, a.shift, o, nz), 1)) {
+      pk = o;
+    } else {
+      nz = 0;
+      pk = s4_step_slice(pk, du, dv, dw, q, a.shift, nz, ovf);
+    }
+  } else {
+    pk = s4_step_unpacked(P, pk, du, dv, dw, q, a.shift, nz, ovf);
+  }
   // (skipping the store of untouched slices, as the S >= 9 kernels do in place, is SLOWER here: 16-byte holes inside
   // 64-byte games turn full-line writes into partial ones -- 2.83 -> 3.05 us at BASELINE config 2)
   if (live) *reinterpret_cast<uint4*>(a.out + g0 * a.stride + off) = pk;
-  const bool any_nz = team_any<4>(nz != 0);
-  if (q == 0 && live) (a.done + g0)[lg] = any_nz ? 0 : 1;
+  // done: the OR of the team's four slices by two quad-permuting DPP ORs (every lane is active here; dead lanes hold
+  // a copy of the last live game), then one byte per game through the workgroup's scalar base + a 32-bit lane offset
+  // (the ballot form cost 8 VALU instructions on the q == 0 lanes, this costs 4 on all)
+  uint32_t t1, t2;
+  asm("s_nop 1\n\tv_or_b32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(t1) : "v"(nz));
+  asm("s_nop 1\n\tv_or_b32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(t2) : "v"(t1));
+  uint8_t* const done_blk = a.done + g0;
+  if (q == 0 && live) done_blk[static_cast<uint32_t>(lg)] = t2 ? 0 : 1;
   // the flag is sticky and only ever set to 1: a lane whose slice overflowed stores it itself (rare), so the common
   // path carries no team reduction for it
   if (__builtin_expect((ovf & ~255) != 0, 0) && a.overflow && live) (a.overflow + g0)[lg] = 1;
@@ -1471,7 +1555,16 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       const int64_t bytes = B * a.in_stride;
       const bool nt = (bytes >= (96ll << 20) || TG_SWITCH("TG_S4_NT_LOADS")) && !TG_SWITCH("TG_S4_NO_NT_LOADS");
       const bool tw = nt && (bytes >= kS4TokenWaitBytes || TG_SWITCH("TG_S4_TOKEN_WAIT")) && !TG_SWITCH("TG_S4_NO_TOKEN_WAIT");
-      const S4StepArgs sa{a.in, a.out, a.actions, a.done, a.overflow, a.B, static_cast<uint32_t>(a.in_stride), a.shift};
+      const S4StepArgs sa{a.in, a.out, a.actions, a.done, a.overflow, a.B, static_cast<uint32_t>(a.in_stride), a.shift,
+                          s4_digits_limit(a.shift)};
+#ifdef TG_AB_SWITCHES
+      if (TG_SWITCH("TG_S4_NO_DIGITS")) {  // the packed form alone
+        if (tw) hipLaunchKernelGGL((s4_step_kernel<true, true, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
+        else if (nt) hipLaunchKernelGGL((s4_step_kernel<true, false, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
+        else hipLaunchKernelGGL((s4_step_kernel<false, false, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
+        return check_launch(fn);
+      }
+#endif
       if (tw) hipLaunchKernelGGL((s4_step_kernel<true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
       else if (nt) hipLaunchKernelGGL((s4_step_kernel<true, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
       else hipLaunchKernelGGL((s4_step_kernel<false, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);

@@ -70,6 +70,42 @@ def test_strassen_replay_golden(golden):
     assert not host(out).any()
 
 
+@pytest.mark.parametrize("shift", [0, 1, 2, 3, 4, -1])
+def test_s4_digit_form_boundaries(shift):
+    """tg_step_i8 at S=4 takes the digit form (one 32-bit multiply-add per row of a slice) only where no byte can
+    carry into its neighbour: every token <= 3, 0 <= shift <= 3, and the slice's L1 norm <= 127 - F^3.  Games placed
+    on both sides of each of those limits -- and slices full of -128 / 127, where a carry WOULD cross -- must equal
+    the oracle bit for bit, flags included."""
+    rng = np.random.default_rng(100 + shift)
+    F3 = max(shift, 3 - shift) ** 3 if 0 <= shift <= 3 else 27
+    limit = 127 - F3
+    B = 64 * 6 + 5
+    st = np.zeros((B, 4, 4, 4), dtype=np.int8)
+    ac = rng.integers(0, 4, size=(B, 12)).astype(np.int8)                  # all tokens <= 3
+    for b in range(B):
+        kind = b % 8
+        for i in range(4):
+            # one big entry per slice puts the slice norm at limit-1, limit, limit+1, 127, 128 (as -128) ...
+            big = [limit - 1, limit, limit + 1, 127, -128, -limit, -(limit + 1), 5][kind]
+            big = int(np.clip(big, -128, 127))
+            st[b, i].flat[rng.integers(0, 16)] = big
+            if kind in (0, 5):                                               # spread the rest of the norm thinly
+                pass
+            elif kind == 7:                                                  # many small entries, norm around the limit
+                st[b, i] = rng.integers(-8, 9, size=(4, 4))
+    ac[3::11, rng.integers(0, 12)] = 4                                       # a token beyond the digit form's vocabulary
+    ac[5::13] = rng.integers(-128, 128, size=ac[5::13].shape)               # wide tokens (negative bytes too)
+    st[7::17] = rng.choice([-128, 127], size=st[7::17].shape)               # every byte at the edge
+    want, want_done, want_ovf = O.step_i8(st, ac, shift=shift)
+    for inplace in (False, True):
+        t = padded(st)
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        out, done = ops.step(t, dev(ac), out=t if inplace else None, overflow=ovf, shift=shift)
+        assert np.array_equal(host(out), want)
+        assert np.array_equal(host(done), want_done) and np.array_equal(host(ovf), want_ovf)
+    assert want_ovf.any() and not want_ovf.all()
+
+
 def test_strassen_dataset_448_golden(golden):
     g = golden("strassen")
     st = padded(g["ds_states"])
