@@ -855,9 +855,13 @@ def generator_valu_instructions(with_basis):
     return None, None
 
 
-def graph_time(fn, dev, reps, samples=5):
+def graph_time(fn, dev, reps, samples=5, warm_ms=60.0):
     """Seconds per call of `fn` (one or more launches on the current stream): `reps` calls captured in a hipGraph,
-    replayed back to back, median over `samples` of (HIP events around one replay) / reps."""
+    replayed back to back, median over `samples` of (HIP events around one replay) / reps.
+    Untimed warm-up: the graph is first replayed back to back for `warm_ms` of GPU time.  After an idle gap (the Python
+    between two workloads is enough) the MI355X runs a VALU-bound kernel ~20 % slower for the first ~50 ms of sustained
+    work (tools/gen_series.py, profiles/r03_generator_series.txt: 34.5 -> 28.3 us per generator launch; the launch- and
+    memory-bound step kernels do not move, tools/step_series.py); the figure reported is the sustained one."""
     for _ in range(3):
         fn()
     cur = torch.cuda.current_stream(dev)
@@ -868,10 +872,15 @@ def graph_time(fn, dev, reps, samples=5):
         for _ in range(reps):
             fn()
     cur.wait_stream(side)
+    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    w0.record()
     g.replay()
+    w1.record()
     torch.cuda.synchronize(dev)
+    one_ms = max(w0.elapsed_time(w1), 1e-3)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(samples + 1)]
-    g.replay()
+    for _ in range(1 + min(2000, int(warm_ms / one_ms))):  # warm-up and timed replays in ONE stream of back-to-back work
+        g.replay()
     for i in range(samples + 1):
         evs[i].record()
         if i < samples:

@@ -143,6 +143,15 @@ __device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t 
 // ---- the factor distribution of the generator (host-filled, passed by value) ----------------
 // The basis sampler draws 32-bit uniforms against `thr`.  The factor generator draws SIXTEEN-bit uniforms,
 // eight per Philox block: a draw d16 selects val[#{t : d16 * 2^16 >= thr[t]}], i.e. d16 is compared with
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a workgroup-scope fence + s_barrier: hipcc puts
+// `s_waitcnt vmcnt(0)` in front of it, i.e. every barrier also waits until all global STORES this wavefront has issued
+// are acknowledged -- for a kernel that streams results out between barriers and never reads them back that drains
+// the write queue (microseconds under load) once per phase.  Use this one where the data exchanged across the barrier
+// lives in LDS and nothing written to global memory is read again by the workgroup.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // thr16[t] = ceil(thr[t] / 2^16) in [0, 65536].  For the packed evaluation (two draws per dword) the
 // thresholds that are always true (thr16 == 0) are folded into `base16` and those never true (65536) are
 // dropped: value = base + sum_{t < nthr} [d16 >= c16[t] + 1] * delta16[t], all int16 replicated in both halves.

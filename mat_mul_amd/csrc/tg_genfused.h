@@ -40,25 +40,36 @@ struct GenArgs {
 #else
 #define TG_GF_ON(bit) true
 #endif
-// Diagnostic build only (-DTG_STAMPS, tools/stamp_genfused.py): workgroups 0..19 record the shader clock at phase
+// Diagnostic build only (-DTG_STAMPS, tools/stamp_genfused.py): workgroups 0, 100, .. 1900 record the shader clock at phase
 // boundaries into the OVERFLOW buffer (24 uint64 per workgroup; B >= 4096), which that build therefore does not use
 // as flags.  Never part of the product or of the A/B library.
 #ifdef TG_STAMPS
 #define TG_STAMP(i)                                                                                             \
   do {                                                                                                          \
     const int tg_stamp_i = (i);                                                                                 \
-    if (blockIdx.x < 20 && threadIdx.x == 0 && tg_stamp_i < 24 && ga.overflow)                                  \
-      reinterpret_cast<unsigned long long*>(ga.overflow)[blockIdx.x * 24 + tg_stamp_i] = __builtin_amdgcn_s_memtime(); \
+    if (blockIdx.x % 100 == 0 && blockIdx.x < 2000 && threadIdx.x == 0 && tg_stamp_i < 24 && ga.overflow)       \
+      reinterpret_cast<unsigned long long*>(ga.overflow)[blockIdx.x / 100 * 24 + tg_stamp_i] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+// the same for lane 0 of the LAST wavefront (a storing one), slots 12 .. 23
+#define TG_STAMP_LAST(i)                                                                                        \
+  do {                                                                                                          \
+    const int tg_stamp_i = 12 + (i);                                                                            \
+    if (blockIdx.x % 100 == 0 && blockIdx.x < 2000 && threadIdx.x == blockDim.x - 64 && tg_stamp_i < 24 && ga.overflow) \
+      reinterpret_cast<unsigned long long*>(ga.overflow)[blockIdx.x / 100 * 24 + tg_stamp_i] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define TG_STAMP(i) \
   do {              \
   } while (0)
+#define TG_STAMP_LAST(i) \
+  do {                   \
+  } while (0)
 #endif
 
+// (token images: only with a basis -- without one the drawn tokens go from registers straight to global memory)
 template <int S>
-constexpr int genfused_lds_bytes(int Rp, int R) {
-  return MGeo<S>::TROWS * (Rp + 16) + MGeo<S>::IMG + 32 + 2 * (((R * 3 * S + 15) & ~15) + 16) + 16;
+constexpr int genfused_lds_bytes(int Rp, int R, bool basis) {
+  return MGeo<S>::TROWS * (Rp + 16) + MGeo<S>::IMG + 32 + (basis ? 2 * (((R * 3 * S + 15) & ~15) + 16) : 0) + 16;
 }
 
 // bytes 16h .. 16h+15 of an S-byte row in global memory (any alignment; nothing past the row is read; bytes >= S are 0)
@@ -114,15 +125,26 @@ __device__ __forceinline__ int exact_target_from_tokens(const uint8_t* tok, int 
 // CHECK = false (host-proved, BASIS = false only): R * max|value|^3 <= 127, so no target entry can leave int8 and the
 // tiles skip their range tracking (the reference's {-1,0,1} with R <= 127).
 // TERN: the distribution is the three-valued one (two thresholds), known on the host.
-template <int S, int KS, bool BASIS, int NW, bool CHECK = true, bool TERN = false>
+// LUT (round 3; host-proved: TERN, no basis, no CHECK, values exactly (-1, 0, 1)): the u and v rows of T hold the
+// ternary codes of lutmul16 (tg_mfma.h) and the tiles look their byte products up -- 8 VALU instructions per 32
+// actions and tile instead of 16 (the byte products were ~40 % of this kernel's instructions).
+// DIRECT (round 3, no basis only): a lane's drawn tokens leave by unaligned global stores from its registers; false = the
+// token image in LDS + a second pass LDS -> global, as with a basis (kept for the A/B library: TG_GF_TOKIMG).
+template <int S, int KS, bool BASIS, int NW, bool CHECK = true, bool TERN = false, bool LUT = false, bool DIRECT = !BASIS>
 __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) {
+  static_assert(!LUT || (TERN && !BASIS && !CHECK), "the lookup form is for the plain ternary generator");
+  static_assert(!DIRECT || !BASIS, "with a basis the tokens are MFMA results: they go through the token image");
   using G = MGeo<S>;
   constexpr int NTHREADS = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) uint8_t mfma_smem[];
   if constexpr (KS != 0) Rp = 32 * KS;
   const int RS = Rp + 16;
   const int R = ga.R, blk = R * G::A3;
-  const int tokbuf_bytes = ((blk + 15) & ~15) + 16;  // [pad + blk] bytes; pad = the block's 16-byte phase in global memory
+  // [pad + blk] bytes; pad = the block's 16-byte phase in global memory.  Without a basis there is no token image: a
+  // lane's drawn tokens are final as they stand and leave by (unaligned) global stores from its registers -- the image
+  // cost 16 ds_write_b8 + 6 shifts per job and lane and a second pass LDS -> global (round 3: the draw's LDS writes
+  // were 4.1 us and the token stores 1.0 us of 32.3 by ablation)
+  const int tokbuf_bytes = DIRECT ? 0 : ((blk + 15) & ~15) + 16;
   int8_t* const T = reinterpret_cast<int8_t*>(mfma_smem);
   uint8_t* const img = mfma_smem + G::TROWS * RS;
   uint8_t* const tokimg = img + G::IMG + 32;  // two buffers of tokbuf_bytes
@@ -177,6 +199,7 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
         fa = row_fragment16<S>(ga.basis + ((g * 3 + x) * S + (col < S ? col : S - 1)) * S, h);
       uint32_t Dw[4] = {0, 0, 0, 0};  // factor bytes of this lane's blocks (two dwords per block)
       uint32_t Kw[4] = {0, 0, 0, 0};  // the same as tokens (value + shift)
+      uint32_t Cw[4] = {0, 0, 0, 0};  // LUT: what goes to T (codes for u and v, the factor bytes for w)
       bool need = active && draws;
       uint32_t attempt = 0;
       while (true) {
@@ -200,6 +223,20 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
                 Kw[2 * b] = __builtin_amdgcn_perm(pk_add_u16(P[1], shp), pk_add_u16(P[0], shp), 0x06040200u);
                 Kw[2 * b + 1] = __builtin_amdgcn_perm(pk_add_u16(P[3], shp), pk_add_u16(P[2], shp), 0x06040200u);
               }
+              if constexpr (LUT) {  // what T gets for this mode: u -> value + 1, v -> 4 m(value), w -> the value
+                if (x < 2) {        // (wave-uniform)
+                  uint32_t c0 = Kw[2 * b], c1 = Kw[2 * b + 1];  // the tokens ARE value + 1 under the usual shift
+                  if (ga.shift != 1) {
+                    c0 = __builtin_amdgcn_perm(pk_add_u16(P[1], one16), pk_add_u16(P[0], one16), 0x06040200u);
+                    c1 = __builtin_amdgcn_perm(pk_add_u16(P[3], one16), pk_add_u16(P[2], one16), 0x06040200u);
+                  }
+                  Cw[2 * b] = x == 0 ? c0 : __builtin_amdgcn_perm(0u, kLutCodeV, c0);
+                  Cw[2 * b + 1] = x == 0 ? c1 : __builtin_amdgcn_perm(0u, kLutCodeV, c1);
+                } else {
+                  Cw[2 * b] = Dw[2 * b];
+                  Cw[2 * b + 1] = Dw[2 * b + 1];
+                }
+              }
             }
           }
         }
@@ -211,6 +248,10 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
         ++attempt;
       }
       v4i F, K;
+      if constexpr (LUT) {  // from here on "the factor bytes" are what T gets
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Dw[j] = Cw[j];
+      }
       if constexpr (kSwap) {  // the upper half's block becomes elements 8..15 of the lower half's fragment
         const auto s0 = __builtin_amdgcn_permlane32_swap(Dw[0], 0u, false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(Dw[1], 0u, false, false);
@@ -231,17 +272,36 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
         constexpr int KBOTH = kSwap ? 0 : (S - 16 < 16 ? S - 16 : 16), KLOW = S < 16 ? S : 16;
         if (active && holds && TG_GF_ON(2)) {
           int8_t* const tcol = T + (x * S + kbase) * RS + r;
-          uint8_t* const trow = tk + (3 * r + x) * S + kbase;
 #pragma unroll
-          for (int k = 0; k < KBOTH; ++k) {
-            tcol[k * RS] = static_cast<int8_t>(static_cast<uint32_t>(F[k >> 2]) >> (8 * (k & 3)));
-            trow[k] = static_cast<uint8_t>(static_cast<uint32_t>(K[k >> 2]) >> (8 * (k & 3)));
-          }
+          for (int k = 0; k < KBOTH; ++k) tcol[k * RS] = static_cast<int8_t>(static_cast<uint32_t>(F[k >> 2]) >> (8 * (k & 3)));
           if (kbase == 0) {
 #pragma unroll
-            for (int k = KBOTH; k < KLOW; ++k) {
-              tcol[k * RS] = static_cast<int8_t>(static_cast<uint32_t>(F[k >> 2]) >> (8 * (k & 3)));
-              trow[k] = static_cast<uint8_t>(static_cast<uint32_t>(K[k >> 2]) >> (8 * (k & 3)));
+            for (int k = KBOTH; k < KLOW; ++k) tcol[k * RS] = static_cast<int8_t>(static_cast<uint32_t>(F[k >> 2]) >> (8 * (k & 3)));
+          }
+        }
+        if constexpr (!DIRECT) {
+          if (active && holds && TG_GF_ON(2)) {
+            uint8_t* const trow = tk + (3 * r + x) * S + kbase;
+#pragma unroll
+            for (int k = 0; k < KBOTH; ++k) trow[k] = static_cast<uint8_t>(static_cast<uint32_t>(K[k >> 2]) >> (8 * (k & 3)));
+            if (kbase == 0) {
+#pragma unroll
+              for (int k = KBOTH; k < KLOW; ++k) trow[k] = static_cast<uint8_t>(static_cast<uint32_t>(K[k >> 2]) >> (8 * (k & 3)));
+            }
+          }
+        } else if (active && holds && TG_GF_ON(16)) {
+          // the vector's tokens: KLOW bytes (lane half 0) / KBOTH bytes (lane half 1) at (3 r + x) S + kbase of the game's
+          // block, any alignment: whole dwords as unaligned global stores, then the tail bytes
+          int8_t* const gp = ga.actions + g * blk + (3 * r + x) * S + kbase;
+          const int nb = kbase == 0 ? KLOW : KBOTH;  // lane-half uniform
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            if (4 * d + 4 <= KBOTH || (kbase == 0 && 4 * d + 4 <= KLOW)) {
+              reinterpret_cast<UnalignedU32*>(gp + 4 * d)->v = static_cast<uint32_t>(K[d]);
+            } else {
+#pragma unroll
+              for (int t = 0; t < 3; ++t)
+                if (4 * d + t < nb) gp[4 * d + t] = static_cast<int8_t>(static_cast<uint32_t>(K[d]) >> (8 * t));
             }
           }
         }
@@ -308,7 +368,7 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
       copy_chunks(img, reinterpret_cast<uint8_t*>(out), NFULL, t, nthr);
       if (G::TAIL != 0 && t < G::TAIL) out[16 * NFULL + t] = static_cast<int8_t>(img[16 * NFULL + t]);
     }
-    if (TG_GF_ON(16)) {
+    if (!DIRECT && TG_GF_ON(16)) {
       const int pad = token_pad(g);
       uint8_t* const gbase = reinterpret_cast<uint8_t*>(ga.actions + g * blk) - pad;
       const int total = pad + blk;
@@ -330,7 +390,7 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
   int orslot = 0;
   auto wg_or = [&](int v) {
     if (v) atomicOr(&orw[orslot], static_cast<uint32_t>(v));
-    __syncthreads();
+    lds_barrier();  // (not __syncthreads(): that would wait for the acknowledgement of every store of the previous game)
     const int r = static_cast<int>(orw[orslot]);
     if (tid == 0) orw[(orslot + 3) & 3] = 0;  // the word of the previous barrier
     orslot = (orslot + 1) & 3;
@@ -342,10 +402,12 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
   int64_t prev = -1, cur = blockIdx.x;
   bool prev_exact = false;
   int buf = 0;
-  int stamp = 2;
+  int stamp = 2, stamp2 = 0;
   (void)stamp;
+  (void)stamp2;
   while (true) {
     const bool has_cur = cur < ga.B;
+    TG_STAMP_LAST(stamp2++);  // last wavefront: loop top (B2 passed)
     // stores of the previous game: by everybody when nothing follows, else by the wavefronts that draw least
     if (prev >= 0) {
       const uint8_t* const pbuf = tokimg + (buf ^ 1) * tokbuf_bytes;
@@ -353,24 +415,28 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
       else if (light) store_outputs(prev, pbuf, !prev_exact, light_tid, light_threads);
     }
     TG_STAMP(stamp++);  // stores of prev issued (thread 0 belongs to a drawing wavefront: ~ loop top)
+    TG_STAMP_LAST(stamp2++);  // last wavefront: its stores of prev are issued
     if (!has_cur) break;
     uint8_t* const tbuf = tokimg + buf * tokbuf_bytes;
     int big = 0, bad = 0;  // big: factors beyond the byte products (exact fallback); bad: a token left int8 (flag)
-    draw(cur, tbuf + token_pad(cur), big, bad);
+    draw(cur, DIRECT ? nullptr : tbuf + token_pad(cur), big, bad);
     TG_STAMP(stamp++);  // own draw jobs done
+    TG_STAMP_LAST(stamp2++);
     const int verdict = wg_or((big ? 1 : 0) | ((bad & ~255) ? 2 : 0));  // B1: T, token image complete; image reads of prev done
     TG_STAMP(stamp++);  // B1 passed
-    const bool exact = (verdict & 1) != 0;  // workgroup-uniform; rare
+    TG_STAMP_LAST(stamp2++);
+    const bool exact = BASIS && (verdict & 1) != 0;  // workgroup-uniform; rare (drawn values are inside the byte products)
     int flag = 0;
     if (exact) {  // exact byte-wise form from the emitted tokens, straight to global memory
       note_fallback();
       flag = exact_target_from_tokens<S, NTHREADS>(tbuf + token_pad(cur), R, ga.shift, ga.target + cur * ga.out_stride);
     } else {  // column tiles on the matrix cores -> the target image
       int hi = 0, lo = 0;
-      if (TG_GF_ON(4)) accumulate_tiles<S, KS, NW, CHECK>(T, img, Rp, tm, wave, col, h, hi, lo);
+      if (TG_GF_ON(4)) accumulate_tiles<S, KS, NW, CHECK, LUT, (S % 4 != 0)>(T, img, Rp, tm, wave, col, h, hi, lo);
       flag = (hi > 127) | (lo < -128);
     }
     TG_STAMP(stamp++);  // own tiles done
+    TG_STAMP_LAST(stamp2++);
     const bool any_ovf = (wg_or(flag) != 0) | ((verdict & 2) != 0);  // B2: the image is complete, T is free
 #ifndef TG_STAMPS
     if (tid == 0 && any_ovf && ga.overflow) ga.overflow[cur] = 1;

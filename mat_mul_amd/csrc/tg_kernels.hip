@@ -1802,18 +1802,30 @@ int tg_internal_gen_fused(int8_t* target, int8_t* actions, uint8_t* overflow, co
   ga.ablate = getenv("TG_GF_ABLATE") ? atoi(getenv("TG_GF_ABLATE")) : 0;
   wgs_override = getenv("TG_GF_WGS") ? atoi(getenv("TG_GF_WGS")) : 0;
 #endif
+#ifdef TG_AB_SWITCHES
+#define TG_GF_TOKIMG_VARIANT(S_, KS_, BAS_, CHK_) \
+  if (tokimg && !(BAS_)) kern = gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true, kLutShape, false>
+#else
+#define TG_GF_TOKIMG_VARIANT(S_, KS_, BAS_, CHK_) (void)0
+#endif
 #define TG_GF_K(S_, KS_, BAS_, CHK_)                                                               \
   do {                                                                                             \
-    const int ldsb = genfused_lds_bytes<S_>(Rp, R);                                                \
+    const bool tokimg = (BAS_) || TG_SWITCH("TG_GF_TOKIMG");                                       \
+    const int ldsb = genfused_lds_bytes<S_>(Rp, R, tokimg);                                        \
     static OccupancySlots occ;                                                                     \
     if (D.nthr == 2 && KS_ != 0) {  /* the reference's three values: the specialised draw evaluation */ \
-      static OccupancySlots occ3;                                                                  \
-      const int per_cu3 = wgs_override > 0 ? wgs_override : resident_per_cu(gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true>, ldsb, occ3); \
+      static OccupancySlots occ3, occ3l;                                                           \
+      constexpr bool kLutShape = !(BAS_) && !(CHK_);  /* values exactly (-1,0,1): byte products by table lookup */ \
+      const bool lut = kLutShape && lut_values;                                                    \
+      void (*kern)(GenArgs, int) = lut ? gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true, kLutShape>        \
+                                       : gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true>;           \
+      TG_GF_TOKIMG_VARIANT(S_, KS_, BAS_, CHK_);                                                   \
+      const int per_cu3 = wgs_override > 0 ? wgs_override : resident_per_cu(kern, ldsb, lut ? occ3l : occ3); \
       const int64_t resident3 = static_cast<int64_t>(per_cu3) * device_cu_count() * (wgs_override > 0 ? 1 : 2); \
       const int64_t per_wg3 = (B + resident3 - 1) / resident3;                                     \
       const int64_t grid3 = (B + per_wg3 - 1) / per_wg3;                                           \
       (void)hipGetLastError();                                                                     \
-      hipLaunchKernelGGL((gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true>), dim3((unsigned)grid3), dim3(kBlock), ldsb, st, ga, Rp); \
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid3), dim3(kBlock), ldsb, st, ga, Rp);             \
       if (int rc = check_launch(fn)) return rc;                                                    \
       return 1;                                                                                    \
     }                                                                                              \
@@ -1845,6 +1857,7 @@ int tg_internal_gen_fused(int8_t* target, int8_t* actions, uint8_t* overflow, co
   int fmax = 0;
   for (int t = 0; t < D.nv; ++t) fmax = D.val[t] > fmax ? D.val[t] : (-D.val[t] > fmax ? -D.val[t] : fmax);
   const bool in_range = !basis && static_cast<int64_t>(R) * fmax * fmax * fmax <= 127 && !TG_SWITCH("TG_GF_ALWAYS_CHECK");
+  const bool lut_values = D.nv == 3 && D.val[0] == -1 && D.val[1] == 0 && D.val[2] == 1 && !TG_SWITCH("TG_GF_NO_LUT");
   if (S == 9) TG_GF(9);
   if (S == 16) TG_GF(16);
   TG_GF(25);
@@ -2021,13 +2034,19 @@ int tg_step_emit(int8_t* ring, const int8_t* actions, void* out, float* scalars,
   if (reinterpret_cast<uintptr_t>(out) & 15) return fail(TG_ERR_INVALID, "%s: out must be 16-byte aligned", fn);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nxt = head_slot + 1 < T ? head_slot + 1 : 0;
+  // One launch while the model input stays in the caches (65 536 games, T = 4: 9.9 us against 14.3 for step + frames in
+  // float16, 14.4 against 18.4 in float32).  Once the output streams to HBM the frames kernel's fully coalesced
+  // 16-byte-per-thread write stream wins over the fused kernel's 64-byte team runs (2^20 games: 243 against 185 us,
+  // 350 against 320), so from kStreamOutBytes of output on this entry is the two launches.
+  const int64_t out_bytes = B * T * 64 * (out_dtype ? 2 : 4);
   const bool fused = S == 4 && (reinterpret_cast<uintptr_t>(ring) & 3) == 0 && frame_stride_bytes % 4 == 0 &&
-                     game_stride_bytes % 4 == 0 && aligned4(actions) && static_cast<unsigned>(shift + 127) <= 254u;
+                     game_stride_bytes % 4 == 0 && aligned4(actions) && static_cast<unsigned>(shift + 127) <= 254u &&
+                     (out_bytes < tg::kStreamOutBytes || TG_SWITCH("TG_STEP_EMIT_FUSED"));
   if (fused) {
     tg::StepEmitArgs a{ring, actions, out, scalars, done, overflow, B, frame_stride_bytes, game_stride_bytes, T, head_slot, shift, t_step};
     const int64_t blocks = (B * 4 + tg::kBlock - 1) / tg::kBlock;
     if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
-    const bool nt = B * T * 64 * (out_dtype ? 2 : 4) >= tg::kStreamOutBytes || TG_SWITCH("TG_EMIT_NT");
+    const bool nt = out_bytes >= tg::kStreamOutBytes || TG_SWITCH("TG_EMIT_NT");  // (A/B library only, see above)
     const dim3 grid(static_cast<unsigned>(blocks)), block(tg::kBlock);
     (void)hipGetLastError();
 #define TG_SE(OutT_)                                                                              \

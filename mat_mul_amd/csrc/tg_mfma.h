@@ -70,6 +70,22 @@ __device__ __forceinline__ v4i bytemul16(const v4i a, const v4i b) {
   return d;
 }
 
+// The same sixteen products for the ternary vocabulary {-1, 0, 1} by table lookup (gen_fused_kernel<.., LUT>): the u
+// rows of T hold the code u + 1 (0, 1, 2), the v rows the code 4 m(v) with m(-1) = 0, m(+1) = 1, m(0) = 2, so
+// code_u | code_v is a v_perm_b32 selector into an 8-byte pool: selectors 0..2 -> (+1, 0, -1) = u * (-1), 4..6 ->
+// (-1, 0, +1) = u * (+1), and 8..10 (v = 0) replicate the sign bits of pool bytes 1, 3, 5, which are zero.  One v_or_b32
+// (VOP2) + one v_perm_b32 per four products instead of four SDWA multiplies.
+__device__ __forceinline__ v4i lutmul16(const v4i a, const v4i b, uint32_t pool_hi, uint32_t pool_lo) {
+  v4i d;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    d[q] = static_cast<int>(__builtin_amdgcn_perm(pool_hi, pool_lo, static_cast<uint32_t>(a[q]) | static_cast<uint32_t>(b[q])));
+  return d;
+}
+constexpr uint32_t kLutPoolLo = 0x00FF0001u, kLutPoolHi = 0x000100FFu;  // bytes 0..3 = (+1, 0, -1, 0), 4..7 = (-1, 0, +1, 0)
+constexpr uint32_t kLutCodeV = 0x00040800u;                             // v code by u code: bytes (0, 8, 4, 0)
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
 struct __attribute__((packed)) UnalignedU32 { uint32_t v; };  // gfx950 LDS takes unaligned dwords (ds_write_b32)
 
 // ---- the tile phase shared by genf_mfma_kernel and gen_fused_kernel (tg_genfused.h) -----------------------------
@@ -101,7 +117,12 @@ __device__ __forceinline__ void make_tile_map(TileMap<S, NW_>& tm, int RS, int w
 // hi / lo: running max / min of every int32 result of this lane (the int8 range check).
 // CHECK = false: the caller has proved that no result can leave int8 (R * fmax^3 <= 127): the running max / min
 // (sixteen VALU instructions per tile) is dropped and hi / lo stay untouched.
-template <int S, int KS, int NW_, bool CHECK = true>
+// LUT = true: T's u / v rows hold the ternary codes of lutmul16 instead of the factors (w rows: the factors, as ever).
+// BYTES = true (round 3): every result leaves as ONE ds_write_b8 straight from its accumulator register (the low byte of
+// the int32 IS the int8 result; a byte store has no alignment to respect): no packing (12 v_perm_b32 per tile), no
+// half-wave exchange, no v_alignbyte -- ~20 VALU instructions per tile move to the LDS pipe, which has the room (the
+// kernels are bound by VALU issue: SQ_ACTIVE_INST_LDS is a fifth of SQ_ACTIVE_INST_VALU).
+template <int S, int KS, int NW_, bool CHECK = true, bool LUT = false, bool BYTES = false>
 __device__ __forceinline__ void accumulate_tiles(const int8_t* T, uint8_t* img, int Rp, const TileMap<S, NW_>& tm, int wave,
                                                  int col, int h, int& hi, int& lo) {
   using G = MGeo<S>;
@@ -113,6 +134,65 @@ __device__ __forceinline__ void accumulate_tiles(const int8_t* T, uint8_t* img, 
     v4i wa[KS ? KS : 1];
 #pragma unroll
     for (int k = 0; k < KS; ++k) wa[k] = *reinterpret_cast<const v4i*>(T + woff + 32 * k);
+    uint32_t pool_hi = kLutPoolHi, pool_lo = kLutPoolLo;  // (VOP3 on gfx950 takes one scalar operand and no literal)
+    if constexpr (LUT) asm volatile("" : "+v"(pool_hi), "+s"(pool_lo));
+    auto products = [&](const v4i a, const v4i b) {
+      if constexpr (LUT) return lutmul16(a, b, pool_hi, pool_lo);
+      else return bytemul16(a, b);
+    };
+    // the accumulators of one tile: acc[t] = row l = (t & 3) + 8 (t >> 2) + 4 h of this lane's column
+    auto tile_acc = [&](int k) {
+      v16i acc;
+#pragma unroll
+      for (int t2 = 0; t2 < 16; ++t2) acc[t2] = 0;
+      if constexpr (KS != 0) {
+        v4i p[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          p[ks] = products(*reinterpret_cast<const v4i*>(T + uoff[k] + 32 * ks),
+                           *reinterpret_cast<const v4i*>(T + voff[k] + 32 * ks));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa[ks], p[ks], acc, 0, 0, 0);
+      } else {
+        for (int k0 = 0; k0 < Rp; k0 += 32) {
+          const v4i w = *reinterpret_cast<const v4i*>(T + woff + k0);
+          const v4i p = products(*reinterpret_cast<const v4i*>(T + uoff[k] + k0),
+                                 *reinterpret_cast<const v4i*>(T + voff[k] + k0));
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, p, acc, 0, 0, 0);
+        }
+      }
+      if constexpr (CHECK) {
+#pragma unroll
+        for (int t2 = 0; t2 < 16; t2 += 2) {
+          hi = max(max(acc[t2], acc[t2 + 1]), hi);
+          lo = min(min(acc[t2], acc[t2 + 1]), lo);
+        }
+      }
+      return acc;
+    };
+    if constexpr (BYTES) {
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        if (G::NT % NW != 0 && wave + NW * k >= G::NT) break;  // wave-uniform
+        __builtin_amdgcn_sched_barrier(0);
+        const v16i acc = tile_acc(k);
+        if constexpr (CHECK) asm volatile("" : "+v"(hi), "+v"(lo));  // the range of THIS tile is final: one tile live at a time
+        if (ncol[k] >= 0) {
+          // volatile: hipcc otherwise merges neighbouring byte stores back into (unaligned) dwords, packing included
+          volatile lds_u8_t* const dst = (lds_u8_t*)(img + ncol[k] * S + 4 * h);
+#pragma unroll
+          for (int t2 = 0; t2 < 16; ++t2)  // rows valid in both lane halves
+            if ((t2 & 3) + 8 * (t2 >> 2) + 4 < S) dst[(t2 & 3) + 8 * (t2 >> 2)] = static_cast<uint8_t>(acc[t2]);
+          if (h == 0) {
+#pragma unroll
+            for (int t2 = 0; t2 < 16; ++t2)  // rows of the lower half only
+              if ((t2 & 3) + 8 * (t2 >> 2) < S && (t2 & 3) + 8 * (t2 >> 2) + 4 >= S)
+                dst[(t2 & 3) + 8 * (t2 >> 2)] = static_cast<uint8_t>(acc[t2]);
+          }
+        }
+      }
+      return;
+    }
     // one tile -> X[q] = the low bytes of this lane's results for rows l = 8 q + 4 h + (0..3)
     auto tile = [&](int k, uint32_t (&X)[4]) {
       v16i acc;
@@ -122,15 +202,15 @@ __device__ __forceinline__ void accumulate_tiles(const int8_t* T, uint8_t* img, 
         v4i p[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-          p[ks] = bytemul16(*reinterpret_cast<const v4i*>(T + uoff[k] + 32 * ks),
-                            *reinterpret_cast<const v4i*>(T + voff[k] + 32 * ks));
+          p[ks] = products(*reinterpret_cast<const v4i*>(T + uoff[k] + 32 * ks),
+                           *reinterpret_cast<const v4i*>(T + voff[k] + 32 * ks));
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa[ks], p[ks], acc, 0, 0, 0);
       } else {
         for (int k0 = 0; k0 < Rp; k0 += 32) {
           const v4i w = *reinterpret_cast<const v4i*>(T + woff + k0);
-          const v4i p = bytemul16(*reinterpret_cast<const v4i*>(T + uoff[k] + k0),
-                                  *reinterpret_cast<const v4i*>(T + voff[k] + k0));
+          const v4i p = products(*reinterpret_cast<const v4i*>(T + uoff[k] + k0),
+                                 *reinterpret_cast<const v4i*>(T + voff[k] + k0));
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, p, acc, 0, 0, 0);
         }
       }
@@ -278,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) 
 
     // ---- 2. column tiles on the matrix cores, two at a time ----
     int hi = 0, lo = 0;  // running max / min of every result of this lane
-    accumulate_tiles<S, KS>(T, img, Rp, tm, wave, col, h, hi, lo);
+    accumulate_tiles<S, KS, kBlock / 64, true, false, (S % 4 != 0)>(T, img, Rp, tm, wave, col, h, hi, lo);
     const bool any_ovf = __syncthreads_or((hi > 127) | (lo < -128));  // also: the image is complete
 
     // ---- 3. image -> global, 16-byte chunks ----

@@ -40,6 +40,10 @@ for S, B, K in [(9, 9, 6), (16, 6, 5), (25, 3, 7)]:
     tok, tgt = ops.gen_demos(B, S, 40, "cuda:0", seed=3, basis=torch.from_numpy(P_o.astype(np.int8)).cuda(), overflow=ovf)
     assert np.array_equal(tok.cpu().numpy(), tok_o) and np.array_equal(tgt.cpu().numpy(), tgt_o)
     assert np.array_equal(ovf.cpu().numpy(), ovf_o)
+    for shift in (1, 2):   # the plain ternary generator: byte products by table lookup unless TG_GF_NO_LUT
+        tok_o, tgt_o, _ = O.gen_demos_i8(B, S, 40, thr, (-1, 0, 1), shift, seed=5)
+        tok, tgt = ops.gen_demos(B, S, 40, "cuda:0", seed=5, shift=shift)
+        assert np.array_equal(tok.cpu().numpy(), tok_o) and np.array_equal(tgt.cpu().numpy(), tgt_o), (S, shift)
 print("AB_OK")
 '''
 
@@ -89,7 +93,7 @@ def _run(script_text, tmp_path, marker, extra_env=None):
     assert res.returncode == 0 and marker in res.stdout, (res.stdout[-1000:], res.stderr[-3000:])
 
 
-@pytest.mark.parametrize("env_name", ["TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA", "TG_MFMA_MANY_ALWAYS", "TG_NO_FUSED_GEN"])
+@pytest.mark.parametrize("env_name", ["TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA", "TG_MFMA_MANY_ALWAYS", "TG_NO_FUSED_GEN", "TG_GF_NO_LUT", "TG_GF_TOKIMG"])
 def test_ab_switch_paths_stay_exact(env_name, tmp_path):
     """The measurement switches (packed chunks instead of rows; vector ALU instead of the matrix cores) select
     kernels that the product dispatch no longer uses at these shapes -- they must stay bit-exact."""
@@ -147,11 +151,19 @@ for S, B, k in [(4, 70, 8), (4, 5, 3), (16, 9, 4), (9, 19, 5), (25, 3, 3)]:
         x, sc = ops.emit_frames(ring, 1, 4.0, dt)
         want = frames[:, [1, 0, 2]].astype(np.float32)                               # newest first from head slot 1
         assert np.array_equal(x.float().cpu().numpy(), want) and bool((sc == 4.0).all()), (S, dt)
+    # fused step + model input (one kernel at S=4; its non-temporal form is reached through TG_EMIT_NT only)
+    ac1 = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)).astype(np.int8)
+    ring.copy_(dev(frames))
+    x, sc, dn, nxt = ops.step_emit(ring, 1, dev(ac1), 2.0, dtype=torch.float16)
+    new, want_done, _ = O.step_i8(frames[:, 1], ac1)
+    want = frames.copy(); want[:, 2] = new
+    assert nxt == 2 and np.array_equal(host(ring), want) and np.array_equal(host(dn), want_done), S
+    assert np.array_equal(x.float().cpu().numpy(), want[:, [2, 1, 0]].astype(np.float32)), S
 print("STREAM_OK")
 '''
 
 
-@pytest.mark.parametrize("env_name", ["TG_EXPAND_NT", "TG_EXPAND_NO_NT", "TG_COPY_NT1", "TG_COPY_NT2", "TG_COPY_PLAIN", "TG_EMIT_NT"])
+@pytest.mark.parametrize("env_name", ["TG_EXPAND_NT", "TG_EXPAND_NO_NT", "TG_COPY_NT1", "TG_COPY_NT2", "TG_COPY_PLAIN", "TG_EMIT_NT", "TG_STEP_EMIT_FUSED"])
 def test_write_stream_variants_stay_exact(env_name, tmp_path):
     """The non-temporal forms of the write streams -- expand's children (from 128 MiB of children on), the copy's loads and
     stores (by footprint) and the model-input frames (from 128 MiB of output on) -- forced at small batches against the

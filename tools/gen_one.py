@@ -16,5 +16,8 @@ P = ops.sample_basis(B, S, dev, seed=3) if len(sys.argv) > 1 else None
 tok = torch.empty((B, R, 3 * S), dtype=torch.int8, device=dev)
 tgt = ops.alloc_states(B, S, dev)
 ovf = torch.zeros(B, dtype=torch.uint8, device=dev)
-sec = bench.graph_time(lambda: ops.gen_demos(B, S, R, dev, seed=1, basis=P, target=tgt, actions=tok, overflow=ovf), dev, reps=20)
-print(f"{sec * 1e6:.2f} us")
+ts = list(bench.graph_time(lambda: ops.gen_demos(B, S, R, dev, seed=1, basis=P, target=tgt, actions=tok, overflow=ovf), dev, reps=20)
+            for _ in range(9))
+print("in order:", " ".join(f"{t * 1e6:.2f}" for t in ts))
+ts = sorted(ts)
+print(f"{ts[4] * 1e6:.2f} us (median of 9 timings of 20 launches; min {ts[0] * 1e6:.2f}, max {ts[-1] * 1e6:.2f})")

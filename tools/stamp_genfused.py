@@ -36,3 +36,22 @@ for i, n in enumerate(names):
 print("total entry -> last stamp: median", int((st[:, len(names)] - st[:, 0]).median()), "cycles")
 print("per phase, summed over the four games (median workgroup):",
       {k: int(sum(d[:, 1 + 4 * g + j].median() for g in range(4))) for j, k in enumerate(["loop top", "draw", "wait B1", "tiles"])})
+
+# lane 0 of the last wavefront (a storing one): per game: loop top (B2 passed), stores issued, draw done, B1 passed, tiles done
+st2 = ovf.view(torch.int64)[:480].reshape(20, 24)[:, 12:].cpu()
+names2 = []
+for g in range(2):
+    names2 += [f"last wave g{g}: loop top -> stores of prev issued", f"last wave g{g}: draw", f"last wave g{g}: wait B1",
+               f"last wave g{g}: tiles", f"last wave g{g}: tiles done -> next loop top (B2)"]
+d2 = st2[:, 1:] - st2[:, :-1]
+for i, n in enumerate(names2):
+    if i < d2.shape[1]:
+        col = d2[:, i]
+        print(f"{n:55s} median {int(col.median()):7d}  min {int(col.min()):7d}  max {int(col.max()):7d} cycles")
+
+# per stamped workgroup (0, 100, ..., 1900): start relative to the first, duration, and the heavy wavefront's phases
+e = st[:, 0] - st[:, 0].min()
+last = st[:, 1 + 4 * 2 + 1]
+print("workgroup: start (cycles after the first) / entry -> final loop top / draw g0, tiles g0, draw g1, tiles g1 / last wave: stores g1, wait B1 g1")
+for w in range(20):
+    print(f"  wg {100 * w:5d}: {int(e[w]):7d} / {int(last[w] - st[w, 0]):6d} / {int(d[w, 2])}, {int(d[w, 4])}, {int(d[w, 6])}, {int(d[w, 8])} / {int(d2[w, 5])}, {int(d2[w, 7])}")
