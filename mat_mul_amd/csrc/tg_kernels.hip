@@ -982,6 +982,27 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
 // =============================================================================================
 // one chunk: x - (-uv) ... i.e. x + uvn * w, uvn = -u_i v_j; saturating int16 form, 32-bit redo when the range test fails
 // (wfetch: the game's 16 w tokens again, for the redo only -- keeping them would cost four registers on the common path)
+// The digit form of one row (round 3; s4_step_digits has the argument): a row is 16 bytes = four base-256 integers of
+// biased digits, the game's w the four integers Wd[d] = w token dword - shift * 0x01010101, and the update of dword d is
+// ONE multiply-add, X' = X + uvn * Wd[d] -- exact when no digit leaves [0, 255], which the caller guarantees up front:
+// all 48 tokens <= 3 and 0 <= shift <= 3 (wave-uniform, on the scalar unit) bound every |u v w| by F^3, and the row's
+// L1 norm (four v_sad_u8) bounds every |x|.  ~20 VALU instructions per row instead of ~32, and the sixteen that build
+// the int16 weight pairs leave the kernel's common path altogether.  Returns false when this lane's row is not covered.
+__device__ __forceinline__ bool s16_chunk_digits(const uint4& x, int uvn, const uint32_t (&Wd)[4], int limit, uint4& res,
+                                                 uint32_t& cnz) {
+  const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+  uint32_t o[4], l1 = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t xb = xs[d] ^ 0x80808080u;
+    l1 = __builtin_amdgcn_sad_u8(xb, 0x80808080u, l1);
+    o[d] = (xb + static_cast<uint32_t>(uvn) * Wd[d]) ^ 0x80808080u;
+  }
+  res = uint4{o[0], o[1], o[2], o[3]};
+  cnz = o[0] | o[1] | o[2] | o[3];
+  return static_cast<int>(l1) <= limit;
+}
+
 template <class WFetch>
 __device__ __forceinline__ uint4 s16_chunk(const uint4& x, int uvn, const uint32_t (&wp)[8], WFetch wfetch, int shift,
                                            bool wide_shift, uint32_t& cnz, uint32_t& ovf) {
@@ -1032,7 +1053,8 @@ __device__ __forceinline__ uint4 s16_chunk(const uint4& x, int uvn, const uint32
 // ~300 MiB it is neutral to harmful (77 000 games = 301 MiB: 58.7 / 60.3 us, 65 536 games: 50.3 / 52.0, BASELINE config
 // 3: 6.0 / 8.5), from 86 000 games = 336 MiB on it wins (80.0 / 66.4): taken from 320 MiB on.  Without whole-line stores
 // (the S = 25 step as it was: 16-byte pieces) it gains nothing at any size (143.1 / 143.0 us at 32 768 games).
-template <int MODE, bool LINES, bool NTL = false>
+// DIG: rows go through the digit form first (false only in the A/B library: TG_S16_NO_DIGITS).
+template <int MODE, bool LINES, bool NTL = false, bool DIG = true>
 __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyArgs a) {  // (LINES keeps the inputs to the end)
   static_assert(MODE == STEP, "s16_step_kernel: single step only");
   constexpr int QCAP = 64;  // queue entries per wavefront
@@ -1066,10 +1088,23 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
   int8_t* const out = a.out + g * a.out_stride;
   const uint32_t shp = (static_cast<uint32_t>(a.shift) & 0xFFFFu) | (static_cast<uint32_t>(a.shift) << 16);
   const bool wide_shift = static_cast<unsigned>(a.shift + 127) > 254u;  // uniform; factors may exceed 255
-  uint32_t wp[8];
-  unpack_pairs(wq, wp);
+  // digit form (s16_chunk_digits): its precondition on tokens and shift is wave-uniform -- all 48 tokens come by scalar
+  // loads -- so a game either offers it to every row or to none; limit < 0 = not offered
+  const uint4 vq = *reinterpret_cast<const uint4*>(tok + 16);
+  const uint32_t tok_or = uq.x | uq.y | uq.z | uq.w | vq.x | vq.y | vq.z | vq.w | wq.x | wq.y | wq.z | wq.w;
+  const int dig_limit = (DIG && (tok_or & 0xFCFCFCFCu) == 0) ? s4_digits_limit(a.shift) : -1;
+  const uint32_t shrep = static_cast<uint32_t>(a.shift) * 0x01010101u;
+  const uint32_t Wd[4] = {wq.x - shrep, wq.y - shrep, wq.z - shrep, wq.w - shrep};
+  // one row, digit form first; the packed int16 form (its weight pairs built here, off the common path) for the rest
+  auto chunk = [&](const uint4& x, int uvn, uint32_t& cnz) {
+    uint4 res;
+    if (__builtin_expect(s16_chunk_digits(x, uvn, Wd, dig_limit, res, cnz), 1)) return res;
+    uint32_t wp[8];
+    unpack_pairs(wq, wp);
 #pragma unroll
-  for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
+    for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
+    return s16_chunk(x, uvn, wp, wfetch, a.shift, wide_shift, cnz, ovf);
+  };
   auto differs = [](const uint4& x, const uint4& y) { return x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w; };
   // does this lane store chunk (lane, n), given whether it changed and the ballot of the lanes whose chunk n changed?
   auto stores = [&](bool changed, unsigned long long cm) {
@@ -1109,7 +1144,7 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
       const uint4 x = qd[wave][lane];
       const int2 me = qm[wave][lane];
       uint32_t cnz;
-      const uint4 res = s16_chunk(x, me.y, wp, wfetch, a.shift, wide_shift, cnz, ovf);
+      const uint4 res = chunk(x, me.y, cnz);
       nz |= cnz;
       if constexpr (LINES) {
         qd[wave][lane] = res;  // back to the owner, who stores whole lines
@@ -1137,7 +1172,7 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
       uint4 res = pn;
       if (uvn != 0) {
         uint32_t cnz;
-        res = s16_chunk(pn, uvn, wp, wfetch, a.shift, wide_shift, cnz, ovf);
+        res = chunk(pn, uvn, cnz);
         nz |= cnz;
       }
       const bool chg = differs(res, pn);
@@ -1705,6 +1740,17 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       // (round 3 sweep, whole lines without / with them: 512 MiB 129.6 / 99.4 us, 1 GiB 257.6 / 230.0, 1.5 GiB 387.0 / 395.7,
       // 2 GiB 515.5 / 537.3, 4 GiB 1023.5 / 1054.0 -- once the footprint is many times the cache the hint only costs)
       const bool nt_band = B * a.in_stride >= kNtLoadsFromBytes && B * a.in_stride < kNtLoadsToBytes;
+#ifdef TG_AB_SWITCHES
+      if (TG_SWITCH("TG_S16_NO_DIGITS")) {  // the packed int16 form alone
+        if (nt_band || TG_SWITCH("TG_S16_NT_LOADS"))
+          hipLaunchKernelGGL((s16_step_kernel<MODE, true, true, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+        else if (B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES"))
+          hipLaunchKernelGGL((s16_step_kernel<MODE, true, false, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+        else
+          hipLaunchKernelGGL((s16_step_kernel<MODE, false, false, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+        return check_launch(fn);
+      }
+#endif
       if ((nt_band || TG_SWITCH("TG_S16_NT_LOADS")) && !TG_SWITCH("TG_S16_NO_NT_LOADS"))  // (A/B switches: tests)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
       else if ((B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES")) && !TG_SWITCH("TG_S16_NO_LINES"))  // (A/B switch: tests at small batches)
