@@ -76,15 +76,15 @@ STEP_KERNEL = {9: "tg::s9_step_kernel<0>"}
 def step_kernel_name(S: int, B: int) -> str:
     """The kernel tg_step_i8 launches for aligned int8 states (tg_kernels.hip, launch_apply)."""
     MiB = 1 << 20
-    if S == 4:  # non-temporal state loads from 96 MiB of states on, token wait from 384 MiB on
+    if S == 4:  # non-temporal state loads from 96 MiB of states on, token wait from 384 MiB on; last flag: digit form
         b = B * 64
-        return "tg::s4_step_kernel<true, true>" if b >= 384 * MiB else (
-            "tg::s4_step_kernel<true, false>" if b >= 96 * MiB else "tg::s4_step_kernel<false, false>")
+        return "tg::s4_step_kernel<true, true, true>" if b >= 384 * MiB else (
+            "tg::s4_step_kernel<true, false, true>" if b >= 96 * MiB else "tg::s4_step_kernel<false, false, true>")
     if S == 16:  # whole-line stores from 96 MiB of states on, non-temporal state loads in [320 MiB, 1.25 GiB)
         b = B * 4096
         if 320 * MiB <= b < 1280 * MiB:
-            return "tg::s16_step_kernel<0, true, true>"
-        return "tg::s16_step_kernel<0, true, false>" if b >= 96 * MiB else "tg::s16_step_kernel<0, false, false>"
+            return "tg::s16_step_kernel<0, true, true, true>"
+        return "tg::s16_step_kernel<0, true, false, true>" if b >= 96 * MiB else "tg::s16_step_kernel<0, false, false, true>"
     if S == 25:  # 15 632-byte game strides: lines in [96 MiB, 1.25 GiB), nt loads in [320 MiB, 1.25 GiB), plain beyond
         b = B * 15632
         if 320 * MiB <= b < 1280 * MiB:

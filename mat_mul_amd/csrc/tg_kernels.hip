@@ -371,6 +371,21 @@ __device__ __forceinline__ bool s4_step_digits(const uint32_t (&xb)[4], uint32_t
   return wide == 0 && static_cast<int>(l1) <= limit;
 }
 
+// One step on one slice, digit form first and the packed form for the lanes it does not cover (the body shared by
+// tg_expand_i8's child teams and the streamed stepper; s4_step_kernel spells the two halves out around its loads).
+__device__ __forceinline__ uint4 s4_step_tiered(const uint4& in_slice, uint32_t du, uint32_t dv, uint32_t dw, int q, int shift,
+                                                int digits_limit, uint32_t& nz, int& ovf) {
+  uint32_t xb[4];
+  const uint32_t l1 = s4_digits_pre(in_slice, xb);
+  uint4 o;
+  uint32_t dnz = 0;
+  if (__builtin_expect(s4_step_digits(xb, l1, digits_limit, du, dv, dw, q, shift, o, dnz), 1)) {
+    nz |= dnz;
+    return o;
+  }
+  return s4_step_slice(in_slice, du, dv, dw, q, shift, nz, ovf);
+}
+
 // The game's 12 token bytes as three dwords (u | v | w) in every lane of its 4-lane team from ONE dword load per lane:
 // lane q loads dword min(q, 2) and the team exchanges them by DPP quad broadcasts (three v_mov_b32_dpp).  A
 // global_load_dwordx3 per lane asks the memory pipeline for 48 bytes per game where 12 are distinct; with the token
@@ -841,7 +856,7 @@ __global__ __launch_bounds__(kBlock) void s4_expand_kernel(ApplyArgs a, int PB, 
                                                     (__umul24(pl, static_cast<uint32_t>(a.in_stride)) + 16u * q));
   uint32_t nz = 0;
   int ovf = 0;
-  const uint4 o = s4_step_slice(par, du, dv, dw, q, a.shift, nz, ovf);
+  const uint4 o = s4_step_tiered(par, du, dv, dw, q, a.shift, s4_digits_limit(a.shift), nz, ovf);
   int8_t* const dst = a.out + c0 * a.out_stride + (__umul24(lc, static_cast<uint32_t>(a.out_stride)) + 16u * q);
   if (live) {
     if constexpr (NT) store16_nt(dst, o);
@@ -918,6 +933,7 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
     if (!live[n]) g[n] = a.B - 1;  // dead lanes shadow the last game, stores predicated off
     pk[n] = *reinterpret_cast<const uint4*>(a.state + g[n] * a.stride + 16 * q);
   }
+  const int dig_limit = s4_digits_limit(a.shift);
   for (int k = 0; k < a.K; ++k) {
     if (a.ready) {  // relaxed agent-scope poll (bypasses this CU's L1), one address for the wavefront
       uint32_t spins = 0;
@@ -941,7 +957,7 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
       const uint32_t dw = static_cast<uint32_t>(__hip_atomic_load(tp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       uint32_t nz = 0;
       int ovf = 0;
-      pk[n] = s4_step_slice(pk[n], du, dv, dw, q, a.shift, nz, ovf);
+      pk[n] = s4_step_tiered(pk[n], du, dv, dw, q, a.shift, dig_limit, nz, ovf);
       const bool any_nz = team_any<4>(nz != 0);
       const bool any_ovf = team_any<4>((ovf & ~255) != 0);
       if (live[n]) {  // write-through (sc1) stores: visible to other agents once this wavefront's vmcnt drains

@@ -60,4 +60,9 @@ hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-result $R/tools/expand_pr
 ( echo "---- 1048576 parents x 8 children ----"; $OUT/expand_probe 1048576; echo "---- 65536 parents x 8 children ----"; $OUT/expand_probe 65536 ) > $OUT/expand_probe.txt 2> $OUT/expand_probe.err || exit 1
 rm -f $OUT/expand_probe
 python3 $R/tools/aux_time.py > $OUT/aux_ops.txt 2> $OUT/aux_ops.err || exit 1
+# 9. round 3: how the rate of a VALU-bound kernel (the generator) and of the launch- / memory-bound steps moves while the
+#    GPU's clocks settle after an idle gap; game strides of 16- against 128-byte multiples; the generator's phases
+python3 $R/tools/gen_series.py > $OUT/generator_series.txt 2> $OUT/generator_series.err || exit 1
+python3 $R/tools/step_series.py > $OUT/step_series.txt 2> $OUT/step_series.err || exit 1
+python3 $R/tools/stride_ab.py > $OUT/stride_ab.txt 2> $OUT/stride_ab.err || exit 1
 echo profiles done

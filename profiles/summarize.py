@@ -65,7 +65,8 @@ if lf.exists():
 if (src / "share_floor.txt").exists():
     shutil.copy(src / "share_floor.txt", dst / f"{tag}_share_floor.txt")
 for probe, name in (("read_bw_probe", "read_bandwidth"), ("issue_rate_probe", "issue_rates"), ("shader_clock_probe", "shader_clock"),
-                    ("expand_probe", "expand_probe"), ("aux_ops", "aux_ops")):
+                    ("expand_probe", "expand_probe"), ("aux_ops", "aux_ops"), ("generator_series", "generator_series"),
+                    ("step_series", "step_series"), ("stride_ab", "stride_ab")):
     if (src / f"{probe}.txt").exists():
         shutil.copy(src / f"{probe}.txt", dst / f"{tag}_{name}.txt")
 
