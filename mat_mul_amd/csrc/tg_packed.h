@@ -579,6 +579,7 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyAr
   __shared__ __attribute__((aligned(16))) uint32_t or_slots[4];
   __shared__ __attribute__((aligned(16))) uint4 qd[kBlock / 64][QCAP];  // candidate chunks
   __shared__ __attribute__((aligned(16))) int4 qm[kBlock / 64][QCAP];   // (chunk index, uv of its first row, of its second row, -)
+  __shared__ __attribute__((aligned(8))) int uvt[S * S + 3];            // -u_i v_j per row (i, j), 0 behind the last
   const int lt = threadIdx.x, lane = lt & 63, wave = lt >> 6;
   const int64_t g = blockIdx.x;
   const int8_t* const tok = a.actions + g * (3 * S);
@@ -599,6 +600,20 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyAr
     sidx = 2 * S + (q + copy) % S;
   }
   const int tokv = tok[sidx >= 0 ? sidx : 0];
+  // round 3: the product -u_i v_j of every ROW (i, j), once per game instead of twice per chunk: thread lt takes rows
+  // lt, lt + 256, lt + 512 (< S^2) straight from the tokens (two byte loads per row, issued here with everything else),
+  // and a chunk's classification below is one division and two LDS words instead of two divisions, two modulos, four
+  // table reads and two multiplies (the step is bound by instruction issue and barrier latency, not by bandwidth: at
+  // 2 GiB of states 3 to 7 resident workgroups per CU and every store form land on the same 580-610 us)
+  constexpr int NROWT = (S * S + kBlock - 1) / kBlock;
+  int tu[NROWT], tv[NROWT];
+#pragma unroll
+  for (int k = 0; k < NROWT; ++k) {
+    const int row = lt + kBlock * k, rr = row < S * S ? row : S * S - 1;
+    const int i = rr / S, j = rr - i * S;
+    tu[k] = tok[i];
+    tv[k] = tok[S + j];
+  }
   const bool active = lt < G::TSA;
   // (four named chunks, not an array: see s16_step_kernel)
   auto load = [&](int n) {
@@ -620,6 +635,12 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyAr
     if (lt < S) val = -val;
     F[lt] = static_cast<short>(val);
   }
+#pragma unroll
+  for (int k = 0; k < NROWT; ++k) {
+    const int row = lt + kBlock * k;
+    if (row < S * S) uvt[row] = mul24_pinned(a.shift - tu[k], tv[k] - a.shift);  // -u_i v_j
+  }
+  if (lt == 0) uvt[S * S] = 0;  // the row behind the last one (the last chunk's second row)
   const bool inplace = a.in == a.out;
   uint32_t nz = 0, ovf = 0;
   auto differs = [](const uint4& x, const uint4& y) { return x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w; };
@@ -674,19 +695,10 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyAr
   auto enqueue = [&](int n, const uint4& pn, int& uv0, int& uv1, int& slot) {
     const int c = lt + G::TSA * n;
     const bool cv = active && c < G::NCHUNK;
-    const int r0 = (16 * c) / S, l0 = (16 * c) % S;  // row (i, j) of the chunk's first element; the second row is r0 + 1
-    int uv[2];
-#pragma unroll
-    for (int sgm = 0; sgm < 2; ++sgm) {
-      const int row = r0 + sgm;
-      int i = row / S;
-      const int j = row - i * S;
-      if (!cv || i >= S) i = S;  // F[S] == 0: rows past the tensor (and idle chunks) add nothing
-      uv[sgm] = mul24_pinned(F[i], F[S + 1 + j]);
-    }
-    if (l0 + 16 <= S) uv[1] = 0;  // the window does not reach the second row
-    uv0 = uv[0];
-    uv1 = uv[1];
+    const int cc = cv ? c : 0;                        // (idle chunks read row 0 and are zeroed below)
+    const int r0 = (16 * cc) / S, l0 = 16 * cc - S * r0;  // row (i, j) of the chunk's first element; the second row is r0 + 1
+    uv0 = cv ? uvt[r0] : 0;
+    uv1 = (cv && l0 + 16 > S) ? uvt[r0 + 1] : 0;      // 0 when the window does not reach the second row
     const bool cand = (uv0 | uv1) != 0;
     const unsigned long long m = __ballot(cand);
     slot = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
