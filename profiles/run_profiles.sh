@@ -65,4 +65,7 @@ python3 $R/tools/aux_time.py > $OUT/aux_ops.txt 2> $OUT/aux_ops.err || exit 1
 python3 $R/tools/gen_series.py > $OUT/generator_series.txt 2> $OUT/generator_series.err || exit 1
 python3 $R/tools/step_series.py > $OUT/step_series.txt 2> $OUT/step_series.err || exit 1
 python3 $R/tools/stride_ab.py > $OUT/stride_ab.txt 2> $OUT/stride_ab.err || exit 1
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-result $R/tools/expand25_probe.hip -o $OUT/expand25_probe > $OUT/expand25_probe_build.log 2>&1 || exit 1
+$OUT/expand25_probe > $OUT/expand25_probe.txt 2> $OUT/expand25_probe.err || exit 1
+rm -f $OUT/expand25_probe
 echo profiles done

@@ -66,7 +66,7 @@ if (src / "share_floor.txt").exists():
     shutil.copy(src / "share_floor.txt", dst / f"{tag}_share_floor.txt")
 for probe, name in (("read_bw_probe", "read_bandwidth"), ("issue_rate_probe", "issue_rates"), ("shader_clock_probe", "shader_clock"),
                     ("expand_probe", "expand_probe"), ("aux_ops", "aux_ops"), ("generator_series", "generator_series"),
-                    ("step_series", "step_series"), ("stride_ab", "stride_ab")):
+                    ("step_series", "step_series"), ("stride_ab", "stride_ab"), ("expand25_probe", "expand25_probe")):
     if (src / f"{probe}.txt").exists():
         shutil.copy(src / f"{probe}.txt", dst / f"{tag}_{name}.txt")
 
