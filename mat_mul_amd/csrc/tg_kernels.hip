@@ -1616,6 +1616,8 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
         return check_launch(fn);
       }
 #endif
+      // (fewer resident wavefronts, which helps the S = 16 / 25 steps beyond 1.25 GiB, costs here: 2 GiB of states with
+      // 24 / 32 / 48 KB of unused LDS per workgroup: 841 / 942 / 1366 us against 772)
       if (tw) hipLaunchKernelGGL((s4_step_kernel<true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
       else if (nt) hipLaunchKernelGGL((s4_step_kernel<true, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
       else hipLaunchKernelGGL((s4_step_kernel<false, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
@@ -1756,7 +1758,11 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       // (round 3 sweep, whole lines without / with them: 512 MiB 129.6 / 99.4 us, 1 GiB 257.6 / 230.0, 1.5 GiB 387.0 / 395.7,
       // 2 GiB 515.5 / 537.3, 4 GiB 1023.5 / 1054.0 -- once the footprint is many times the cache the hint only costs)
       const bool nt_band = B * a.in_stride >= kNtLoadsFromBytes && B * a.in_stride < kNtLoadsToBytes;
+      // (as at S = 25: beyond 1.25 GiB five workgroups per CU instead of eight -- 2 GiB of states, dynamic LDS 0 / 8 / 14 / 20 /
+      // 26 / 34 KB: 516 / 516 / 515 / 514 / 504 / 506 us)
+      int s16_lds_pad = B * a.in_stride >= kNtLoadsToBytes ? 26000 : 0;
 #ifdef TG_AB_SWITCHES
+      if (getenv("TG_S16_LDS_PAD")) s16_lds_pad = atoi(getenv("TG_S16_LDS_PAD"));
       if (TG_SWITCH("TG_S16_NO_DIGITS")) {  // the packed int16 form alone
         if (nt_band || TG_SWITCH("TG_S16_NT_LOADS"))
           hipLaunchKernelGGL((s16_step_kernel<MODE, true, true, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
@@ -1770,7 +1776,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       if ((nt_band || TG_SWITCH("TG_S16_NT_LOADS")) && !TG_SWITCH("TG_S16_NO_NT_LOADS"))  // (A/B switches: tests)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
       else if ((B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES")) && !TG_SWITCH("TG_S16_NO_LINES"))  // (A/B switch: tests at small batches)
-        hipLaunchKernelGGL((s16_step_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+        hipLaunchKernelGGL((s16_step_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kBlock), s16_lds_pad, st, a);
       else
         hipLaunchKernelGGL((s16_step_kernel<MODE, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
       return check_launch(fn);
@@ -1806,13 +1812,21 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       // 135.4 / 129.9 / 99.0, 977 MiB 279.0 / 273.7 / 210.6, 1.46 GiB 428.5 / 439.6 / 464.4, 1.9 GiB 529.7 / 552.2 / 554.7,
       // 3.8 GiB 1089 / 1152 / 1247: beyond 1.25 GiB the plain form is the best one again)
       const int64_t bytes25 = B * a.in_stride;
+      // Far beyond the caches FEWER resident workgroups stream better (each workgroup reads one 15.6 KB game: with three per
+      // CU instead of seven the HBM side sees fewer concurrent streams): unused dynamic LDS holds the kernel to three.
+      // 2 GiB of states, dynamic LDS 0 / 12 / 20 / 24 / 32 / 40 KB (7 / 6 / 5 / 4 / 3 / 3 per CU): 614 / 617 / 597 / 588 / 574 /
+      // 572 us; two per CU: 751.  (BASELINE config 5's share, 61 MB: 15.0 / 15.1 / - / 16.1 / 16.1 -- there occupancy wins.)
+      int s25_lds_pad = bytes25 >= kNtLoadsToBytes ? 36000 : 0;
+#ifdef TG_AB_SWITCHES
+      if (getenv("TG_S25_LDS_PAD")) s25_lds_pad = atoi(getenv("TG_S25_LDS_PAD"));
+#endif
       const bool nt_band = bytes25 >= kNtLoadsFromBytes && bytes25 < kNtLoadsToBytes;
       if ((nt_band || TG_SWITCH("TG_S25_NT_LOADS")) && !TG_SWITCH("TG_S25_NO_NT_LOADS"))
         hipLaunchKernelGGL((s25_step_kernel<true, true>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
       else if (((bytes25 >= (96ll << 20) && bytes25 < kNtLoadsToBytes) || TG_SWITCH("TG_S25_LINES")) && !TG_SWITCH("TG_S25_NO_LINES"))
         hipLaunchKernelGGL((s25_step_kernel<true, false>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
       else
-        hipLaunchKernelGGL((s25_step_kernel<false, false>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
+        hipLaunchKernelGGL((s25_step_kernel<false, false>), dim3((unsigned)B), dim3(kBlock), s25_lds_pad, st, a);
       return check_launch(fn);
     }
   }
