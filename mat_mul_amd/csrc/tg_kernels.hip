@@ -1774,7 +1774,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       }
 #endif
       if ((nt_band || TG_SWITCH("TG_S16_NT_LOADS")) && !TG_SWITCH("TG_S16_NO_NT_LOADS"))  // (A/B switches: tests)
-        hipLaunchKernelGGL((s16_step_kernel<MODE, true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+        hipLaunchKernelGGL((s16_step_kernel<MODE, true, true>), dim3((unsigned)blocks), dim3(kBlock), s16_lds_pad, st, a);
       else if ((B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES")) && !TG_SWITCH("TG_S16_NO_LINES"))  // (A/B switch: tests at small batches)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kBlock), s16_lds_pad, st, a);
       else
@@ -1822,9 +1822,9 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
 #endif
       const bool nt_band = bytes25 >= kNtLoadsFromBytes && bytes25 < kNtLoadsToBytes;
       if ((nt_band || TG_SWITCH("TG_S25_NT_LOADS")) && !TG_SWITCH("TG_S25_NO_NT_LOADS"))
-        hipLaunchKernelGGL((s25_step_kernel<true, true>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
+        hipLaunchKernelGGL((s25_step_kernel<true, true>), dim3((unsigned)B), dim3(kBlock), s25_lds_pad, st, a);
       else if (((bytes25 >= (96ll << 20) && bytes25 < kNtLoadsToBytes) || TG_SWITCH("TG_S25_LINES")) && !TG_SWITCH("TG_S25_NO_LINES"))
-        hipLaunchKernelGGL((s25_step_kernel<true, false>), dim3((unsigned)B), dim3(kBlock), 0, st, a);
+        hipLaunchKernelGGL((s25_step_kernel<true, false>), dim3((unsigned)B), dim3(kBlock), s25_lds_pad, st, a);
       else
         hipLaunchKernelGGL((s25_step_kernel<false, false>), dim3((unsigned)B), dim3(kBlock), s25_lds_pad, st, a);
       return check_launch(fn);
