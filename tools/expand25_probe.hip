@@ -106,6 +106,11 @@ int main(int argc, char** argv) {
   run("workgroup per parent, k children, nt stores", [&] { hipLaunchKernelGGL((kparent<true, false>), dim3((unsigned)B), dim3(256), 0, s, in, out, k); }, wb + rb);
   run("... plain stores, a barrier per child", [&] { hipLaunchKernelGGL((kparent<false, true>), dim3((unsigned)B), dim3(256), 0, s, in, out, k); }, wb + rb);
   run("... nt stores, a barrier per child", [&] { hipLaunchKernelGGL((kparent<true, true>), dim3((unsigned)B), dim3(256), 0, s, in, out, k); }, wb + rb);
+  for (int pad : {16384, 32768, 49152, 65536}) {  // fewer resident workgroups per CU (unused dynamic LDS)
+    char name[96];
+    snprintf(name, sizeof name, "workgroup per parent, plain stores, %d KB of unused LDS", pad >> 10);
+    run(name, [&] { hipLaunchKernelGGL((kparent<false, false>), dim3((unsigned)B), dim3(256), pad, s, in, out, k); }, wb + rb);
+  }
   run("workgroup per CHILD (parent re-read), plain stores", [&] { hipLaunchKernelGGL((kchild<false>), dim3((unsigned)(B * k)), dim3(256), 0, s, in, out, k); }, wb + rb);
   run("workgroup per CHILD (parent re-read), nt stores", [&] { hipLaunchKernelGGL((kchild<true>), dim3((unsigned)(B * k)), dim3(256), 0, s, in, out, k); }, wb + rb);
   run("workgroup per parent, children laid out child-major, plain", [&] { hipLaunchKernelGGL((kparent_cm<false>), dim3((unsigned)B), dim3(256), 0, s, in, out, k, B); }, wb + rb);
