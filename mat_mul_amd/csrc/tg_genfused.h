@@ -292,18 +292,25 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
         } else if (active && holds && TG_GF_ON(16)) {
           // the vector's tokens: KLOW bytes (lane half 0) / KBOTH bytes (lane half 1) at (3 r + x) S + kbase of the game's
           // block, any alignment: whole dwords as unaligned global stores, then the tail bytes
+          // As FEW store instructions and lane transactions as possible: these stores are scattered (a lane's bytes lie 3 S
+          // bytes from its neighbour's) and the CU's write path takes them one lane at a time -- one more dword store per job
+          // cost 3.7 us of the 28.6 us launch (measured).  So: the widest unaligned pieces (16, 8, 4 bytes), then single bytes.
           int8_t* const gp = ga.actions + g * blk + (3 * r + x) * S + kbase;
-          const int nb = kbase == 0 ? KLOW : KBOTH;  // lane-half uniform
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            if (4 * d + 4 <= KBOTH || (kbase == 0 && 4 * d + 4 <= KLOW)) {
-              reinterpret_cast<UnalignedU32*>(gp + 4 * d)->v = static_cast<uint32_t>(K[d]);
-            } else {
-#pragma unroll
-              for (int t = 0; t < 3; ++t)
-                if (4 * d + t < nb) gp[4 * d + t] = static_cast<int8_t>(static_cast<uint32_t>(K[d]) >> (8 * t));
+          struct __attribute__((packed)) P16 { uint32_t v[4]; };
+          struct __attribute__((packed)) P8 { uint32_t v[2]; };
+          auto put = [&](int nb) {  // nb: compile-time after inlining (KLOW / KBOTH)
+            int o = 0;
+            if (nb - o >= 16) {  // (written out: for a byte-aligned address hipcc splits the 16 bytes into two 8-byte stores)
+              const v4u_t q{static_cast<uint32_t>(K[0]), static_cast<uint32_t>(K[1]), static_cast<uint32_t>(K[2]), static_cast<uint32_t>(K[3])};
+              asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(gp), "v"(q) : "memory");
+              o = 16;
             }
-          }
+            if (nb - o >= 8) { *reinterpret_cast<P8*>(gp + o) = P8{{static_cast<uint32_t>(K[o >> 2]), static_cast<uint32_t>(K[(o >> 2) + 1])}}; o += 8; }
+            if (nb - o >= 4) { reinterpret_cast<UnalignedU32*>(gp + o)->v = static_cast<uint32_t>(K[o >> 2]); o += 4; }
+            for (; o < nb; ++o) gp[o] = static_cast<int8_t>(static_cast<uint32_t>(K[o >> 2]) >> (8 * (o & 3)));
+          };
+          if (kbase == 0) put(KLOW);
+          else put(KBOTH);
         }
       } else {
         // D[a][r] = sum_i M_x[a][i] f_r[i]: one int8 MFMA; this lane gets a = (t & 3) + 8 (t >> 2) + 4 h of action r
@@ -352,10 +359,16 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
       const uint4 q1 = *reinterpret_cast<const uint4*>(src + 16 * (c1 < n ? c1 : n - 1));
       const uint4 q2 = *reinterpret_cast<const uint4*>(src + 16 * (c2 < n ? c2 : n - 1));
       const uint4 q3 = *reinterpret_cast<const uint4*>(src + 16 * (c3 < n ? c3 : n - 1));
-      *reinterpret_cast<uint4*>(dst + 16 * c0) = q0;
-      if (c1 < n) *reinterpret_cast<uint4*>(dst + 16 * c1) = q1;
-      if (c2 < n) *reinterpret_cast<uint4*>(dst + 16 * c2) = q2;
-      if (c3 < n) *reinterpret_cast<uint4*>(dst + 16 * c3) = q3;
+      // (unsigned 32-bit offsets from the wave-uniform base, each made opaque so that hipcc does not fold them into 64-bit
+      // per-lane pointers: the stores take the scalar-base form)
+      auto st16 = [&](uint32_t off, const uint4& q) {
+        asm volatile("" : "+v"(off));
+        *reinterpret_cast<uint4*>(dst + off) = q;
+      };
+      st16(16u * static_cast<uint32_t>(c0), q0);
+      if (c1 < n) st16(16u * static_cast<uint32_t>(c1), q1);
+      if (c2 < n) st16(16u * static_cast<uint32_t>(c2), q2);
+      if (c3 < n) st16(16u * static_cast<uint32_t>(c3), q3);
     }
   };
 
