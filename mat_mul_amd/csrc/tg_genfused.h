@@ -72,24 +72,34 @@ constexpr int genfused_lds_bytes(int Rp, int R, bool basis) {
   return MGeo<S>::TROWS * (Rp + 16) + MGeo<S>::IMG + 32 + (basis ? 2 * (((R * 3 * S + 15) & ~15) + 16) : 0) + 16;
 }
 
-// bytes 16h .. 16h+15 of an S-byte row in global memory (any alignment; nothing past the row is read; bytes >= S are 0)
+// bytes 16h .. 16h+15 of an S-byte row in global memory (any alignment; nothing past the row is read; bytes >= S are 0).
+// As few load instructions as possible (round 3: scattered accesses are paid per instruction): 8-byte pieces while they fit
+// the row, single bytes for the rest -- three instructions at S = 25 (8 for both lane halves, 8 for the lower, 1 for the upper)
+// where dword pieces took seven.
 template <int S>
 __device__ __forceinline__ v4i row_fragment16(const int8_t* row, int h) {
-  v4i f;
+  struct __attribute__((packed)) P8 { uint32_t lo, hi; };
+  uint32_t w[4] = {0, 0, 0, 0};
+  auto half = [&](auto hc) {  // the lane half as a compile-time constant: every piece's validity is known
+    constexpr int H = decltype(hc)::value;
 #pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    uint32_t w = 0;
-    const int k0 = 16 * h + 4 * d;
-    if (k0 + 3 < S) {
-      __builtin_memcpy(&w, row + k0, 4);
-    } else {
+    for (int p = 0; p < 2; ++p) {
+      constexpr int k0base = 16 * H;
+      const int k0 = k0base + 8 * p;
+      if (k0 + 7 < S) {
+        const P8 v = *reinterpret_cast<const P8*>(row + k0);
+        w[2 * p] = v.lo;
+        w[2 * p + 1] = v.hi;
+      } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (k0 + t < S) w |= static_cast<uint32_t>(static_cast<uint8_t>(row[k0 + t])) << (8 * t);
+        for (int t = 0; t < 8; ++t)
+          if (k0 + t < S) w[2 * p + (t >> 2)] |= static_cast<uint32_t>(static_cast<uint8_t>(row[k0 + t])) << (8 * (t & 3));
+      }
     }
-    f[d] = static_cast<int>(w);
-  }
-  return f;
+  };
+  if (h == 0) half(std::integral_constant<int, 0>{});
+  else half(std::integral_constant<int, 1>{});
+  return v4i{static_cast<int>(w[0]), static_cast<int>(w[1]), static_cast<int>(w[2]), static_cast<int>(w[3])};
 }
 
 // The exact form of one game from its EMITTED tokens in LDS (any factor magnitude): the fallback of gen_fused_kernel
