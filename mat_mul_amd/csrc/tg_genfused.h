@@ -138,12 +138,11 @@ __device__ __forceinline__ int exact_target_from_tokens(const uint8_t* tok, int 
 // LUT (round 3; host-proved: TERN, no basis, no CHECK, values exactly (-1, 0, 1)): the u and v rows of T hold the
 // ternary codes of lutmul16 (tg_mfma.h) and the tiles look their byte products up -- 8 VALU instructions per 32
 // actions and tile instead of 16 (the byte products were ~40 % of this kernel's instructions).
-// DIRECT (round 3, no basis only): a lane's drawn tokens leave by unaligned global stores from its registers; false = the
-// token image in LDS + a second pass LDS -> global, as with a basis (kept for the A/B library: TG_GF_TOKIMG).
-template <int S, int KS, bool BASIS, int NW, bool CHECK = true, bool TERN = false, bool LUT = false, bool DIRECT = !BASIS>
+// DIRECT (round 3): a lane's tokens leave by unaligned global stores from its registers; false = the token image in LDS + a
+// second pass LDS -> global (kept for the A/B library: TG_GF_TOKIMG).
+template <int S, int KS, bool BASIS, int NW, bool CHECK = true, bool TERN = false, bool LUT = false, bool DIRECT = true>
 __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) {
   static_assert(!LUT || (TERN && !BASIS && !CHECK), "the lookup form is for the plain ternary generator");
-  static_assert(!DIRECT || !BASIS, "with a basis the tokens are MFMA results: they go through the token image");
   using G = MGeo<S>;
   constexpr int NTHREADS = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) uint8_t mfma_smem[];
@@ -330,7 +329,8 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, F, acc, 0, 0, 0);
         if (active && TG_GF_ON(2)) {
           int8_t* const tcol = T + (x * S + 4 * h) * RS + r;
-          uint8_t* const trow = tk + (3 * r + x) * S + 4 * h;
+          uint8_t* const trow = DIRECT ? nullptr : tk + (3 * r + x) * S + 4 * h;
+          (void)trow;
           const int lim = x < 2 ? G::UVLIM : 127, lim_lo = x < 2 ? -G::UVLIM : -128;
           int fmx = 0, fmn = 0;  // range of the emitted factors: ONE test per job instead of five operations per value
           auto emit = [&](int t) {  // register t = row a0 + 4 h, a0 = (t & 3) + 8 (t >> 2)
@@ -339,8 +339,40 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
             fmx = max(fmx, f);
             fmn = min(fmn, f);
             tcol[a0 * RS] = static_cast<int8_t>(f);
-            trow[a0] = static_cast<uint8_t>(f + ga.shift);
+            if constexpr (!DIRECT) trow[a0] = static_cast<uint8_t>(f + ga.shift);
           };
+          if constexpr (DIRECT) {
+            // The tokens straight to global memory, in as few store instructions as the plain generator's (scattered stores
+            // are paid per instruction): register group q holds the four consecutive rows 8 q + 4 h + (0..3); two
+            // v_permlane32_swap hand the lower lane half rows 0..15 and the upper half rows 16..31 of the action's vector,
+            // which leave as 16 | 8 + 1 bytes at S = 25 (three instructions; a dword per group took four).
+            if (TG_GF_ON(16)) {
+              uint32_t X[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                X[q] = pack4(acc[4 * q] + ga.shift, acc[4 * q + 1] + ga.shift, acc[4 * q + 2] + ga.shift, acc[4 * q + 3] + ga.shift);
+              const auto s02 = __builtin_amdgcn_permlane32_swap(X[0], X[2], false, false);  // upper half's X0 <-> lower half's X2
+              const auto s13 = __builtin_amdgcn_permlane32_swap(X[1], X[3], false, false);
+              // lower half: s02 = (own X0: rows 0..3, the upper half's X0: rows 4..7), s13 = (own X1: 8..11, upper's X1: 12..15)
+              // upper half: s02 = (the lower half's X2: rows 16..19, own X2: 20..23), s13 = (lower's X3: 24..27, own X3: 28..31)
+              const int K[4] = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
+              int8_t* const gp = ga.actions + g * blk + (3 * r + x) * S + 16 * h;
+              struct __attribute__((packed)) P8 { uint32_t v[2]; };
+              auto put = [&](int nb) {
+                int o = 0;
+                if (nb - o >= 16) {
+                  const v4u_t qv{static_cast<uint32_t>(K[0]), static_cast<uint32_t>(K[1]), static_cast<uint32_t>(K[2]), static_cast<uint32_t>(K[3])};
+                  asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(gp), "v"(qv) : "memory");
+                  o = 16;
+                }
+                if (nb - o >= 8) { *reinterpret_cast<P8*>(gp + o) = P8{{static_cast<uint32_t>(K[o >> 2]), static_cast<uint32_t>(K[(o >> 2) + 1])}}; o += 8; }
+                if (nb - o >= 4) { reinterpret_cast<UnalignedU32*>(gp + o)->v = static_cast<uint32_t>(K[o >> 2]); o += 4; }
+                for (; o < nb; ++o) gp[o] = static_cast<int8_t>(static_cast<uint32_t>(K[o >> 2]) >> (8 * (o & 3)));
+              };
+              if (h == 0) put(S < 16 ? S : 16);
+              else put(S - 16 < 0 ? 0 : (S - 16 < 16 ? S - 16 : 16));
+            }
+          }
 #pragma unroll
           for (int t = 0; t < 16; ++t)
             if ((t & 3) + 8 * (t >> 2) + 4 < S) emit(t);  // valid in both lane halves
@@ -452,7 +484,13 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
     int flag = 0;
     if (exact) {  // exact byte-wise form from the emitted tokens, straight to global memory
       note_fallback();
-      flag = exact_target_from_tokens<S, NTHREADS>(tbuf + token_pad(cur), R, ga.shift, ga.target + cur * ga.out_stride);
+      if constexpr (DIRECT) {  // the tokens are in global memory: every wavefront's stores must have landed first (vmcnt + barrier)
+        __syncthreads();
+        flag = exact_target_from_tokens<S, NTHREADS>(reinterpret_cast<const uint8_t*>(ga.actions + cur * blk), R, ga.shift,
+                                                     ga.target + cur * ga.out_stride);
+      } else {
+        flag = exact_target_from_tokens<S, NTHREADS>(tbuf + token_pad(cur), R, ga.shift, ga.target + cur * ga.out_stride);
+      }
     } else {  // column tiles on the matrix cores -> the target image
       int hi = 0, lo = 0;
       if (TG_GF_ON(4)) accumulate_tiles<S, KS, NW, CHECK, LUT, (S % 4 != 0)>(T, img, Rp, tm, wave, col, h, hi, lo);

@@ -1880,13 +1880,13 @@ int tg_internal_gen_fused(int8_t* target, int8_t* actions, uint8_t* overflow, co
 #endif
 #ifdef TG_AB_SWITCHES
 #define TG_GF_TOKIMG_VARIANT(S_, KS_, BAS_, CHK_) \
-  if (tokimg && !(BAS_)) kern = gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true, kLutShape, false>
+  if (tokimg) kern = gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true, kLutShape, false>
 #else
 #define TG_GF_TOKIMG_VARIANT(S_, KS_, BAS_, CHK_) (void)0
 #endif
 #define TG_GF_K(S_, KS_, BAS_, CHK_)                                                               \
   do {                                                                                             \
-    const bool tokimg = (BAS_) || TG_SWITCH("TG_GF_TOKIMG");                                       \
+    const bool tokimg = TG_SWITCH("TG_GF_TOKIMG") && D.nthr == 2 && KS_ != 0;  /* (A/B library: the LDS token image) */ \
     const int ldsb = genfused_lds_bytes<S_>(Rp, R, tokimg);                                        \
     static OccupancySlots occ;                                                                     \
     if (D.nthr == 2 && KS_ != 0) {  /* the reference's three values: the specialised draw evaluation */ \
