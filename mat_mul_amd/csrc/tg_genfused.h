@@ -2,7 +2,8 @@
 //
 // create_synthetic_demo (utils.py:203-233) / _create_synthetic_demos (datasets.py:124-142) for S = 9, 16, 25:
 //   Philox -> factor bytes in registers -> [change of basis: one int8 MFMA per (mode, 32 actions)] -> the transposed
-//   factor image T[x][r] and the token image in LDS -> the accumulation tiles of tg_mfma.h -> target + tokens out.
+//   factor image T[x][r] in LDS, the tokens straight to global memory (round 3) -> the accumulation tiles of
+//   tg_mfma.h -> the target image -> target out.
 // Round 1 ran three kernels (gen_tokens_kernel, basis_tokens_mfma_kernel, genf_mfma_kernel): the tokens made a round
 // trip through memory twice (19.7 MB written, transformed in place, re-read at S=25, R=64, B=4096) and the token
 // kernel burnt a 32-bit Philox lane per 3-way draw.  Here the factors never leave the chip before they are final:
@@ -11,7 +12,7 @@
 // Draw phase, one job = (mode x, 32 actions) per wavefront pass.  The lane mapping IS the int8 MFMA B-fragment
 // mapping -- lane (col, h) owns elements k = 16h .. 16h+15 of the vector of action r0 + col -- so the change of basis
 // D[a][r] = sum_i M_x[a][i] f_r[i] takes the drawn bytes as they stand (A fragment = row `col` of M_x, read from
-// global memory), and without a basis the same registers go straight to T and to the token image.  One Philox block
+// global memory), and without a basis the same registers go straight to T and -- as tokens -- to global memory.  One Philox block
 // is eight 16-bit draws evaluated two at a time with packed int16 ops (draw_block16); a lane runs the blocks of its
 // half (S = 25: blocks 2h, 2h+1; S <= 16: block h, handed to the lower half by v_permlane32_swap).  A vector that
 // comes out all zero is redrawn (attempt + 1) by its two lanes; the wavefront loops while any vector needs it
@@ -127,8 +128,9 @@ __device__ __forceinline__ int exact_target_from_tokens(const uint8_t* tok, int 
 //     draw(g0) | B1 | tiles(g0) | B2 | stores(g0) + draw(g1) | B1 | tiles(g1) | B2 | stores(g1) + draw(g2) | ...
 // The stores of a game (LDS images -> global memory, fire and forget) are issued by the wavefronts that have the
 // fewest draw jobs of the next game (3 Rp/32 jobs over 4 wavefronts: at R = 64 two wavefronts draw twice, the other two
-// draw once and store), so the memory phase hides behind the next game's Philox arithmetic.  The token image is double
-// buffered (draw(g+1) writes while stores(g) read); the target image and T are free again at B1 / B2 respectively.
+// draw once and store), so the memory phase hides behind the next game's Philox arithmetic.  The target image and T are
+// free again at B1 / B2 respectively.  (Round 2 also kept a double-buffered token image in LDS; since round 3 a lane's
+// tokens leave from its registers inside the draw phase -- DIRECT below -- and the image exists in the A/B library only.)
 //
 // NW wavefronts per workgroup: 4, or 6 when the 3 Rp/32 draw jobs divide by 6 (R = 64: one job per wavefront instead of
 // two wavefronts drawing twice while two wait, and 20 tiles as 4+4+3+3+3+3 instead of 5 each).
