@@ -873,6 +873,7 @@ def graph_time(fn, dev, reps, samples=5, warm_ms=60.0):
             fn()
     cur.wait_stream(side)
     w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g.replay()  # (the first replay uploads the graph: not a measure of its length)
     w0.record()
     g.replay()
     w1.record()
