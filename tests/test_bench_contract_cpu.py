@@ -114,3 +114,26 @@ def test_wrong_world_size_is_refused():
     res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], env=env,
                          capture_output=True, text=True, timeout=120)
     assert res.returncode != 0 and "WORLD_SIZE" in res.stderr
+
+
+def test_step_kernel_names_exist_in_the_library():
+    """bench.step_kernel_name says which kernel tg_step_i8 launches for a workload (the roofline object quotes it and
+    profiles/traffic_rNN.json is matched by it).  Every name it can return must be a kernel of the built library -- a
+    renamed template parameter (round 3 added the digit-form flag) would otherwise silently drop `frac_traffic`."""
+    import subprocess
+
+    import bench
+    from mat_mul_amd import build
+
+    lib = build.build()
+    nm = subprocess.run(["nm", "-C", str(lib)], capture_output=True, text=True)
+    if nm.returncode != 0:
+        pytest.skip("nm not available")
+    MiB = 1 << 20
+    names = set()
+    for S, game in ((4, 64), (16, 4096), (25, 15632)):
+        for nbytes in (1 * MiB, 100 * MiB, 330 * MiB, 400 * MiB, 1300 * MiB, 2100 * MiB):
+            names.add(bench.step_kernel_name(S, max(1, nbytes // game)))
+    assert len(names) >= 9
+    for name in names:
+        assert f"void {name}(" in nm.stdout, name
