@@ -88,8 +88,8 @@ def step_kernel_name(S: int, B: int) -> str:
     if S == 25:  # 15 632-byte game strides: lines in [96 MiB, 1.25 GiB), nt loads in [320 MiB, 1.25 GiB), plain beyond
         b = B * 15632
         if 320 * MiB <= b < 1280 * MiB:
-            return "tg::s25_step_kernel<true, true>"
-        return "tg::s25_step_kernel<true, false>" if 96 * MiB <= b < 1280 * MiB else "tg::s25_step_kernel<false, false>"
+            return "tg::s25_step_kernel<true, true, false>"
+        return "tg::s25_step_kernel<true, false, false>" if 96 * MiB <= b < 1280 * MiB else "tg::s25_step_kernel<false, false, false>"
     return STEP_KERNEL.get(S, "tg::slow_kernel<0>")
 
 
@@ -767,6 +767,44 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
             also[-1]["valu_note"] = ("SQ_INSTS_VALU of the committed PMC pass x 4 issue cycles / (1024 SIMDs x 2.4 GHz x the time "
                                      "measured here); issue alone (measured 4.3 cycles per VOP3 instruction, "
                                      "profiles/r02_issue_rates.txt) would read %.2f" % (insts * 4.3 / (SIMDS * SHADER_CLOCK_HZ * sec)))
+    # the step that loads only what the action touches (tg_step_tracked_i8: the count of non-zero entries is carried, so the
+    # zero test needs no pass over the game): against tg_step_i8 on the same schedule, both by hipGraph replay of whole
+    # cycles (the state and the count are back at their start after every replay: checked)
+    for s2, b2, reps in ((16, 8192, 64), (16, 1 << 17, 32), (16, 1 << 19, 16), (25, 4096, 64), (25, 1 << 15, 32), (25, 139264, 16)):
+        start, sched, _ = make_demo_schedule(b2, s2, 8, dev, 1, 0)
+        L = len(sched)
+        st_full, st_tr = ops.alloc_states(b2, s2, dev), ops.alloc_states(b2, s2, dev)
+        st_full.copy_(start)
+        st_tr.copy_(start)
+        nnz0 = ops.done(start, want_nnz=True)[1]
+        nnz = nnz0.clone()
+        dn = torch.zeros(b2, dtype=torch.uint8, device=dev)
+        pos = [0]
+
+        def full():
+            ops.step(st_full, sched[pos[0] % L], out=st_full, done=dn)
+            pos[0] += 1
+
+        def tracked():
+            ops.step_tracked(st_tr, sched[pos[0] % L], nnz, done=dn)
+            pos[0] += 1
+
+        pos[0] = 0
+        t_full = graph_time(full, dev, reps=reps)
+        while pos[0] % L:  # (graph_time's three eager warm-up calls left the schedule mid-cycle: finish it)
+            full()
+        pos[0] = 0
+        t_tr = graph_time(tracked, dev, reps=reps)
+        while pos[0] % L:
+            tracked()
+        torch.cuda.synchronize(dev)
+        ok = bool(torch.equal(st_tr, start)) and bool(torch.equal(nnz, nnz0)) and bool(torch.equal(st_full, start))
+        also.append({"workload": f"TRACKED tg_step_tracked_i8: S={s2} batch={b2} ({b2 * (-(-s2 ** 3 // 16) * 16) >> 20} MiB of states), in "
+                                 "place, the count of non-zero entries carried: only the rows the action touches are loaded",
+                     "ok": ok, "value": round(b2 / t_tr, 1), "unit": "steps/s", "us_per_launch": round(t_tr * 1e6, 2),
+                     "us_tg_step_i8": round(t_full * 1e6, 2), "gain": round(t_full / t_tr, 3)})
+        del st_full, st_tr, start, sched
+        torch.cuda.empty_cache()
     # get_child_states with k > 1 (act.py:266-275, the shape MCTS expansion calls): k children per parent in one launch;
     # bytes = parent read + k x (child written + tokens read + done + changed)
     for s2, b2 in ((4, 65536), (4, 1 << 20), (9, 32768), (16, 8192), (25, 4096)):

@@ -71,6 +71,16 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
                uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes, int shift,
                tg_stream_t stream);
 
+/* The in-place step that reads only what the action touches (round 3).  tg_step_i8 must read every byte of a game to
+ * answer "is it all zero?"; here the caller carries nnz[b] (int32, EXACT number of non-zero entries of game b on entry:
+ * tg_done_i8 computes it, a reset knows it) and the step updates it, so only the chunks whose rows have u_i v_j != 0 are
+ * loaded and stored, and done[b] = (nnz[b] == 0).  Same state, done and overflow as tg_step_i8(state, state, ...).
+ * Replaces get_child_states k=1,T=1 + tensor_factorized per game (act.py:266-275, utils.py:181-188) for an env that keeps
+ * its games resident.  S = 25 takes the sparse kernel (aligned states); every other shape runs tg_step_i8 + the count
+ * inside this call. */
+int tg_step_tracked_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_t* done, uint8_t* overflow,
+                       int64_t B, int S, int64_t game_stride_bytes, int shift, tg_stream_t stream);
+
 /* K sequential steps with the state resident on chip.  actions: int8 (B,K,3S).
  * done_step[b] (int32) = first step index whose post-state is all zero, or -1.
  * Replaces SyntheticDemoDataset._take_actions (datasets.py:144-153) / K calls of tg_step_i8. */

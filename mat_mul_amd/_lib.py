@@ -43,6 +43,7 @@ SIGNATURES = {
     "tg_expand_keyed_i8": [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i, _p],
     "tg_copy_i8": [_p, _p, _i64, _i, _i64, _i64, _p],
     "tg_done_i8": [_p, _p, _p, _i64, _i, _i64, _p],
+    "tg_step_tracked_i8": [_p, _p, _p, _p, _p, _i64, _i, _i64, _i, _p],
     "tg_reset_matmul_i8": [_p, _i64, _i, _i64, _p],
     "tg_reset_broadcast_i8": [_p, _p, _i64, _i, _i64, _p],
     "tg_gen_from_factors_i8": [_p, _p, _p, _i64, _i, _i, _i64, _i, _p],

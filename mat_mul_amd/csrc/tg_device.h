@@ -143,6 +143,21 @@ __device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t 
 // ---- the factor distribution of the generator (host-filled, passed by value) ----------------
 // The basis sampler draws 32-bit uniforms against `thr`.  The factor generator draws SIXTEEN-bit uniforms,
 // eight per Philox block: a draw d16 selects val[#{t : d16 * 2^16 >= thr[t]}], i.e. d16 is compared with
+// inclusive prefix sum over the 64 lanes of a wavefront, all in the VALU (DPP row shifts and row broadcasts)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+// the wavefront's total of a per-lane integer (uniform)
+__device__ __forceinline__ int wave_sum(int x) {
+  return __builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_scan(static_cast<uint32_t>(x))), 63);
+}
+
 // Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a workgroup-scope fence + s_barrier: hipcc puts
 // `s_waitcnt vmcnt(0)` in front of it, i.e. every barrier also waits until all global STORES this wavefront has issued
 // are acknowledged -- for a kernel that streams results out between barriers and never reads them back that drains

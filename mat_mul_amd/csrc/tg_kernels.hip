@@ -1209,6 +1209,95 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
 }
 
 // =============================================================================================
+// tg_step_tracked_i8 at S = 16 (round 3; s25_tracked_kernel in tg_packed.h has the argument): the in-place step that
+// loads only the rows the action touches -- row (i, j) changes iff u_i v_j != 0, which the tokens alone decide: ~9 % of the
+// rows, in ~28 % of the game's 128-byte lines -- with the number of non-zero entries carried per game.
+// One wavefront per game as in s16_step_kernel; the candidate rows' INDICES are compacted into a queue of up to 256
+// entries (every row: never flushed), lane k takes entries k, k + 64, ... with all their loads in flight together,
+// then per row: count the non-zero bytes, apply (digit form first, packed int16 form behind it), count again, store.
+// =============================================================================================
+__global__ __launch_bounds__(kBlock, 8) void s16_tracked_kernel(ApplyArgs a, int32_t* nnz) {
+  constexpr int NW = kBlock / 64;
+  __shared__ __attribute__((aligned(8))) int2 qm[NW][256];  // (row index i * 16 + j, -u_i v_j)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  int64_t g = static_cast<int64_t>(blockIdx.x) * NW + wave;
+  const bool live = g < a.B;
+  if (!live) g = a.B - 1;
+  const int8_t* tok = a.actions + g * 48;
+  int8_t* const st = a.out + g * a.out_stride;
+  const int nnz_in = nnz[g];
+  const uint4 uq = *reinterpret_cast<const uint4*>(tok);
+  const uint4 vq = *reinterpret_cast<const uint4*>(tok + 16);
+  const uint4 wq = *reinterpret_cast<const uint4*>(tok + 32);
+  auto wfetch = [&]() { return *reinterpret_cast<const uint4*>(tok + 32); };
+  const int vj = tok[16 + (lane & 15)] - a.shift;
+  const int r = lane >> 4;
+  const uint32_t shp = (static_cast<uint32_t>(a.shift) & 0xFFFFu) | (static_cast<uint32_t>(a.shift) << 16);
+  const bool wide_shift = static_cast<unsigned>(a.shift + 127) > 254u;
+  const uint32_t tok_or = uq.x | uq.y | uq.z | uq.w | vq.x | vq.y | vq.z | vq.w | wq.x | wq.y | wq.z | wq.w;
+  const int dig_limit = (tok_or & 0xFCFCFCFCu) == 0 ? s4_digits_limit(a.shift) : -1;
+  const uint32_t shrep = static_cast<uint32_t>(a.shift) * 0x01010101u;
+  const uint32_t Wd[4] = {wq.x - shrep, wq.y - shrep, wq.z - shrep, wq.w - shrep};
+  uint32_t ovf = 0;
+  auto chunk = [&](const uint4& x, int uvn, uint32_t& cnz) {
+    uint4 res;
+    if (__builtin_expect(s16_chunk_digits(x, uvn, Wd, dig_limit, res, cnz), 1)) return res;
+    uint32_t wp[8];
+    unpack_pairs(wq, wp);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
+    return s16_chunk(x, uvn, wp, wfetch, a.shift, wide_shift, cnz, ovf);
+  };
+  // ---- candidate rows -> the queue (indices only) ----
+  const uint32_t ud[4] = {uq.x, uq.y, uq.z, uq.w};
+  int total = 0;  // wave-uniform
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(ud[n]), 8 * r, 8);  // -(u_i), i = r + 4 n
+    const int uvn = ui * vj;
+    const bool cand = uvn != 0;
+    const unsigned long long m = __ballot(cand);
+    const int slot = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
+    if (cand) qm[wave][slot] = int2{lane + 64 * n, uvn};
+    total += __builtin_popcountll(m);
+  }
+  __builtin_amdgcn_wave_barrier();  // (LDS serves one wavefront's accesses in order)
+  // ---- dense passes: entries lane, lane + 64, ...; a pass's loads first ----
+  int delta = 0;
+  const int npass = (total + 63) >> 6;  // uniform; 1 for the reference's factor distribution
+  for (int k0 = 0; k0 < npass; k0 += 2) {
+    int2 me[2];
+    uint4 x[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = lane + 64 * (k0 + k);
+      me[k] = qm[wave][e < total ? e : 0];
+      if (e >= total) me[k].x = -1;
+      x[k] = *reinterpret_cast<const uint4*>(st + 16 * (me[k].x < 0 ? 0 : me[k].x));
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (me[k].x >= 0) {
+        uint32_t cnz;
+        const uint4 res = chunk(x[k], me[k].y, cnz);
+        delta += nz_bytes16(res) - nz_bytes16(x[k]);
+        if (live && (res.x != x[k].x || res.y != x[k].y || res.z != x[k].z || res.w != x[k].w))
+          *reinterpret_cast<uint4*>(st + 16 * me[k].x) = res;
+      }
+    }
+  }
+  delta = wave_sum(delta);
+  const bool wovf = __ballot(ovf != 0) != 0;
+  if (lane == 0 && live) {
+    const int n = nnz_in + delta;
+    nnz[g] = n;
+    a.done[g] = n == 0 ? 1 : 0;
+    if (a.overflow && wovf) a.overflow[g] = 1;
+  }
+}
+
+// =============================================================================================
 // tg_step_stream_i8, S = 16: one wavefront per game, the game's 4 KiB live in 16 VGPRs per lane for all K steps (lane
 // (r, j) owns rows (i = r + 4 n, j), as in s16_step_kernel).  A step reads 48 token bytes and writes through only the
 // rows the action changed (9 % with the reference's vocabulary) plus `done`: the launch-per-step kernel re-reads
@@ -2040,6 +2129,43 @@ int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8
     default: hipLaunchKernelGGL(tg::s4_stream_kernel<8>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
   }
   return check_launch(fn);
+}
+
+constexpr int64_t kTrackedSparse25 = 2048;  // games (placed by tools/tracked_time.py sweeps)
+
+int tg_step_tracked_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_t* done, uint8_t* overflow, int64_t B,
+                       int S, int64_t game_stride_bytes, int shift, tg_stream_t stream) {
+  const char* fn = "tg_step_tracked_i8";
+  if (int rc = validate_common(fn, B, S, game_stride_bytes)) return rc;
+  if (B == 0) return TG_OK;
+  if (!state || !actions || !nnz || !done) return fail(TG_ERR_INVALID, "%s: null pointer", fn);
+  if (reinterpret_cast<uintptr_t>(nnz) & 3) return fail(TG_ERR_INVALID, "%s: nnz must be 4-byte aligned", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (S == 25 && aligned16(state) && game_stride_bytes % 16 == 0 && static_cast<unsigned>(shift + 127) <= 254u &&
+      B <= 0x7fffffffLL) {
+    // sparse kernel from kTrackedSparse25 games on, fewer: the full step's kernel with the count updated (one round trip
+    // instead of two).  Measured, tg_step_i8 / full + count / sparse: 512 games 5.0 / 5.8 / 8.1 us, 1 024 6.1 / 7.1 / 8.3,
+    // 2 048 8.5 / 10.7 / 10.0, 4 096 14.9 / 17.0 / 13.1, 32 768 102 / - / 65, 139 264 (2 GiB) 574 / - / 303
+    tg::ApplyArgs a{state, state, actions, done, nnz, nullptr, overflow, B, game_stride_bytes, game_stride_bytes, S, 1, shift};
+    (void)hipGetLastError();
+    if ((B >= kTrackedSparse25 || TG_SWITCH("TG_TRACKED_SPARSE")) && !TG_SWITCH("TG_TRACKED_FULL"))
+      hipLaunchKernelGGL(tg::s25_tracked_kernel, dim3(static_cast<unsigned>((B + 3) / 4)), dim3(tg::kBlock), 0, st, a, nnz);
+    else
+      hipLaunchKernelGGL((tg::s25_step_kernel<false, false, true>), dim3(static_cast<unsigned>(B)), dim3(tg::kBlock), 0, st, a);
+    return check_launch(fn);
+  }
+  if (S == 16 && aligned16(state) && aligned16(actions) && game_stride_bytes % 16 == 0 && B <= 0x7fffffffLL) {
+    // The sparse kernel pays two dependent round trips for ~28 % of the lines (measured, tg_step_i8 / this: 2 048 games 3.3 /
+    // 3.5 us, 8 192 5.8 / 6.5, 12 288 11.1 / 8.4, 32 768 26.7 / 16.6, 131 072 99.7 / 73.7, 2 GiB 504 / 296).  The full step's
+    // kernel with the count added was no better at the small end (3.8 / 6.6 us): one kernel for every batch.
+    tg::ApplyArgs a{state, state, actions, done, nullptr, nullptr, overflow, B, game_stride_bytes, game_stride_bytes, S, 1, shift};
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tg::s16_tracked_kernel, dim3(static_cast<unsigned>((B + 3) / 4)), dim3(tg::kBlock), 0, st, a, nnz);
+    return check_launch(fn);
+  }
+  // other sizes and layouts: the full step, then the count (two launches inside this call; same results)
+  if (int rc = tg_step_i8(state, state, actions, done, overflow, B, S, game_stride_bytes, shift, stream)) return rc;
+  return tg_done_i8(state, done, nnz, B, S, game_stride_bytes, stream);
 }
 
 int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,

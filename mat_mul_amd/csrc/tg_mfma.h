@@ -393,16 +393,6 @@ __global__ __launch_bounds__(kBlock) void genf_mfma_kernel(ApplyArgs a, int Rp) 
 // are NOT written: their done_step is set to kNeedsExact and the lattice kernels (tg_rows.h / tg_packed.h),
 // launched right after with ApplyArgs::only_flagged, redo exactly those games (counted in g_many_handovers).
 // =============================================================================================
-// inclusive prefix sum over the 64 lanes of a wavefront, all in the VALU (DPP row shifts and row broadcasts)
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
-  x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false);  // row_shr:1
-  x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, false);  // row_shr:2
-  x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, false);  // row_shr:4
-  x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, false);  // row_shr:8
-  x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-  x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-  return x;
-}
 
 struct FunctionalWeights {
   int uv[2][2][32];  // [functional][u or v][index]: odd, 11 bits, signed: pu*pv fits 22 bits (24-bit multiplies)

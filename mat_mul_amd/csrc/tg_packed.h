@@ -547,6 +547,13 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
   }
 }
 
+// number of non-zero bytes of a dword (v_bcnt accumulates)
+__device__ __forceinline__ int nz_bytes(uint32_t x, int acc) {
+  const uint32_t m = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+  return __builtin_popcount(m) + acc;
+}
+__device__ __forceinline__ int nz_bytes16(const uint4& q) { return nz_bytes(q.x, nz_bytes(q.y, nz_bytes(q.z, nz_bytes(q.w, 0)))); }
+
 // =============================================================================================
 // S = 25 single step without the staging round trip of packed_kernel (STEP, one action, one workgroup per game).
 // packed_kernel brings the raw tokens to LDS, scans them (barrier), turns them into the int16 tables (barrier),
@@ -569,8 +576,11 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
 // 128-byte-multiple stride -- so the eight chunks of a line are eight consecutive lanes from lane (-(o + 250 n)) mod 8 on;
 // lines that straddle two wavefronts or two games stay partial) -- and, beyond the Infinity Cache, the state is read by
 // non-temporal loads.
-template <bool LINES, bool NTL>
+// TRACK (tg_step_tracked_i8 below the batch size where its sparse kernel pays): the same full step with the game's carried
+// count of non-zero entries (a.done_step doubles as the nnz array) updated from the candidate chunks, done = (nnz == 0).
+template <bool LINES, bool NTL, bool TRACK = false>
 __global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyArgs a) {  // (6 spills at 64 VGPRs)
+  static_assert(!TRACK || !LINES, "the tracked form is the cache-resident variant");
   constexpr int S = 25;
   using G = PGeo<S, kBlock>;
   static_assert(G::NSEG == 2 && G::NCH == 4 && G::FSTRIDE <= kBlock, "s25_step_kernel geometry");
@@ -580,8 +590,13 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyAr
   __shared__ __attribute__((aligned(16))) uint4 qd[kBlock / 64][QCAP];  // candidate chunks
   __shared__ __attribute__((aligned(16))) int4 qm[kBlock / 64][QCAP];   // (chunk index, uv of its first row, of its second row, -)
   __shared__ __attribute__((aligned(8))) int uvt[S * S + 3];            // -u_i v_j per row (i, j), 0 behind the last
+  __shared__ int dsum;                                                  // TRACK: the workgroup's nnz delta
   const int lt = threadIdx.x, lane = lt & 63, wave = lt >> 6;
   const int64_t g = blockIdx.x;
+  const int nnz_in = (TRACK && lt == 0) ? a.done_step[g] : 0;
+  if (TRACK && lt == 0) dsum = 0;  // (the barrier behind the tables orders it)
+  int delta = 0;
+  (void)delta;
   const int8_t* const tok = a.actions + g * (3 * S);
   const int8_t* const in = a.in + g * a.in_stride;
   int8_t* const out = a.out + g * a.out_stride;
@@ -723,6 +738,7 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyAr
     uint32_t cnz;
     const uint4 res = chunk(x, c, uv0, uv1, cnz);
     nz |= cnz;
+    if constexpr (TRACK) delta += nz_bytes16(res) - nz_bytes16(x);  // (the tail chunk's bytes past the tensor are zero in both)
     // in place, a chunk the action left as it was needs no store
     if (!inplace || differs(res, x)) store_chunk<G::TAIL>(out + 16 * c, res, G::TAIL != 0 && c == G::NCHUNK - 1);
   };
@@ -776,13 +792,207 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyAr
     direct(2, p2, u20, u21);
     direct(3, p3, u30, u31);
   }
+  if constexpr (TRACK) {
+    delta = wave_sum(delta);
+    if (lane == 0 && delta) atomicAdd(&dsum, delta);
+  }
   const uint32_t both = block_or2((nz != 0 ? 1u : 0u) | (ovf != 0 ? 2u : 0u), or_slots);
+  if constexpr (TRACK) {
+    if (lt == 0) {
+      const int n = nnz_in + dsum;
+      a.done_step[g] = n;
+      a.done[g] = n == 0 ? 1 : 0;
+      if (a.overflow && (both & 2u)) a.overflow[g] = 1;
+    }
+    return;
+  }
   if (lt == 0) {
     a.done[g] = (both & 1u) ? 0 : 1;
     if (a.overflow && (both & 2u)) a.overflow[g] = 1;
   }
 }
 
+
+// =============================================================================================
+// tg_step_tracked_i8 at S = 25 (round 3): the in-place step that reads ONLY what the action touches.
+// The zero test is what makes tg_step_i8 read every byte of a game; with the number of non-zero entries CARRIED per game
+// (nnz: exact on entry, updated here) the step needs the chunks whose rows have u_i v_j != 0 -- ~14 % of them under the
+// reference's factor distribution, in ~25 % of the game's 128-byte lines (a row block i with u_i = 0 is never touched) --
+// and done = (nnz == 0).  The price is a second, dependent memory round trip (tokens -> which chunks -> those chunks),
+// which the resident workgroups of a CU hide from each other.
+// Structure of s25_step_kernel: tokens -> the w windows (F) and the row products (uvt) -> barrier -> every thread
+// classifies its four chunk INDICES (no data yet) -> candidates into the wavefront's queue -> dense pass: lane k LOADS
+// the chunk of entry k, counts its non-zero bytes, applies the action (chunk arithmetic of s25_step_kernel), counts
+// again, stores when changed -> the workgroup's nnz delta and overflow flag through LDS.
+// =============================================================================================
+// One WAVEFRONT per game (four games per workgroup, no workgroup barrier: every table is written and read by its own
+// wavefront, and LDS serves one wavefront's accesses in order).  With a workgroup per game the launch was bound by two
+// dependent round trips times two rounds of workgroups (14.6 us at 4 096 games, no better than the full step); a
+// wavefront per game keeps 8 192 games resident, so BASELINE config 5's share is ONE round.
+// The queue holds 192 entries (three per lane: the loads of a dense pass are all in flight together -- with one entry per
+// lane and a pass per 64 candidates the ~140 candidates of a game cost three dependent round trips); it is flushed (a
+// dense pass) whenever the next batch of candidates would not fit.
+__global__ __launch_bounds__(kBlock, 7) void s25_tracked_kernel(ApplyArgs a, int32_t* nnz) {
+  constexpr int S = 25, NW = kBlock / 64;
+  using G = PGeo<S, kBlock>;
+  // queue entries per lane / per wavefront: the loads of a dense pass are all in flight together.  (Measured with 1 / 2 /
+  // 3 per lane at 4 096, 32 768 and 139 264 games: a loop with one entry per lane and a flush per 64 candidates 13.0 /
+  // 59.6 / 289 us, three per lane 12.9 / 64.5 / 296 us -- and an unrolled classification with in-line flushes for 1 or 2 per
+  // lane 20 / 129 / 473 us: the flush must stay the rare case, its code out of the instruction stream.)
+  constexpr int QPL = 3, QCAP = 64 * QPL;
+  constexpr int WLEN = 2 * G::WE, NCL = (G::NCHUNK + 63) / 64, NRW = (S * S + 63) / 64;
+  __shared__ __attribute__((aligned(16))) short Fw[NW][(WLEN + 7) & ~7];  // two periodic copies of w (the second shifted by one)
+  __shared__ __attribute__((aligned(16))) int4 qm[NW][QCAP];              // (chunk index, uv of its first row, of its second row, -)
+  __shared__ __attribute__((aligned(8))) int uvt[NW][S * S + 3];          // -u_i v_j per row (i, j), 0 behind the last
+  __shared__ __attribute__((aligned(4))) int8_t tokb[NW][3 * S + 1];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  int64_t g = static_cast<int64_t>(blockIdx.x) * NW + wave;
+  const bool live = g < a.B;
+  if (!live) g = a.B - 1;  // a dead wavefront shadows the last game; nothing of it is stored
+  const int8_t* const tok = a.actions + g * (3 * S);
+  int8_t* const st = a.out + g * a.out_stride;
+  const int nnz_in = nnz[g];  // (requested now: its round trip must not come behind the last dense pass)
+  // ---- the game's 75 tokens -> LDS; tables from there ----
+  tokb[wave][lane] = tok[lane];
+  if (lane + 64 < 3 * S) tokb[wave][lane + 64] = tok[lane + 64];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int q = lane + 64 * k;
+    if (q < WLEN) {
+      const int copy = q >= G::WE;
+      const int qq = q - copy * G::WE;
+      Fw[wave][q] = static_cast<short>(tokb[wave][2 * S + (qq + copy) % S] - a.shift);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NRW; ++k) {
+    const int row = lane + 64 * k;
+    if (row < S * S) {
+      const int i = row / S, j = row - i * S;
+      uvt[wave][row] = mul24_pinned(a.shift - tokb[wave][i], tokb[wave][S + j] - a.shift);  // -u_i v_j
+    }
+  }
+  if (lane == 0) uvt[wave][S * S] = 0;
+  __builtin_amdgcn_wave_barrier();
+
+  int delta = 0;
+  uint32_t ovf = 0;
+  // one candidate chunk (already loaded): count, apply, count, store
+  auto touch = [&](int c, int uv0, int uv1, const uint4& x) {
+    const bool tail = G::TAIL != 0 && c == G::NCHUNK - 1;
+    const int l0 = (16 * c) % S, hi = S - l0;  // elements k < hi belong to the window's first row
+    const uint32_t* wp = reinterpret_cast<const uint32_t*>(Fw[wave] + (l0 & 1) * G::WE + (l0 & ~1));
+    uint32_t wraw[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) wraw[p] = wp[p];
+    const int c0 = max(-32767, min(32767, uv0)), c1 = max(-32767, min(32767, uv1));
+    const uint32_t pr0 = __builtin_amdgcn_perm(static_cast<uint32_t>(c0), static_cast<uint32_t>(c0), 0x05040100u);
+    const uint32_t pr1 = __builtin_amdgcn_perm(static_cast<uint32_t>(c1), static_cast<uint32_t>(c1), 0x05040100u);
+    uint32_t A[8];
+    unpack_pairs(x, A);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint32_t pr = (2 * p + 1 < hi) ? pr0 : ((2 * p >= hi) ? pr1 : __builtin_amdgcn_perm(pr1, pr0, 0x07060100u));
+      A[p] = pk_mad_i16_sat(pr, wraw[p], A[p]);
+    }
+    uint32_t c16 = 0, cnz = 0;
+    uint4 res = pack_pairs(A, cnz, c16);
+    if (__builtin_expect((c16 & 0xFF00FF00u) != 0, 0)) {  // rare: the chunk again in 32 bits (wrapped bytes + flag)
+      const uint32_t pd[4] = {x.x, x.y, x.z, x.w};
+      uint32_t rd[4];
+      int o32 = 0;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        int e[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int k = 4 * d + t;
+          const int w = static_cast<short>(wraw[k >> 1] >> (16 * (k & 1)));
+          e[t] = sbyte(pd[d], t) + (k < hi ? uv0 : uv1) * w;
+          o32 |= e[t] + 128;
+        }
+        rd[d] = pack4(e[0], e[1], e[2], e[3]);
+      }
+      res = uint4{rd[0], rd[1], rd[2], rd[3]};
+      ovf |= static_cast<uint32_t>(o32) & ~255u;
+    }
+    if (tail) {  // bytes past the tensor: zero on entry (load_chunk), their rows i >= S add nothing; keep them out of the count
+      res.z &= 0x000000FFu;
+      res.w = 0;
+    }
+    delta += nz_bytes16(res) - nz_bytes16(x);
+    if (live && (res.x != x.x || res.y != x.y || res.z != x.z || res.w != x.w)) store_chunk<G::TAIL>(st + 16 * c, res, tail);
+  };
+  auto dense_pass = [&](int n) {  // n entries of the queue: lane k takes entries k, k + 64, ...; ALL their loads first
+    __builtin_amdgcn_wave_barrier();
+    int4 me[QPL];
+    uint4 x[QPL];
+#pragma unroll
+    for (int k = 0; k < QPL; ++k) {
+      const int e = lane + 64 * k;
+      me[k] = qm[wave][e < n ? e : 0];
+      if (e >= n) me[k].x = -1;
+    }
+#pragma unroll
+    for (int k = 0; k < QPL; ++k) {
+      const int c = me[k].x < 0 ? 0 : me[k].x;
+      x[k] = load_chunk<G::TAIL>(st + 16 * c, G::TAIL != 0 && c == G::NCHUNK - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < QPL; ++k)
+      if (me[k].x >= 0) touch(me[k].x, me[k].y, me[k].z, x[k]);
+    __builtin_amdgcn_wave_barrier();
+  };
+  // ---- which chunks does the action touch?  (indices only.)  All sixteen classifications first -- their table reads in
+  // flight together -- then the ballots; the queue is flushed when the next batch would not fit (dense factors only).
+  // (only the candidate BITS are kept across the two stages -- the products of a candidate are read again when it is
+  // queued; thirty-two of them in registers spilled)
+  auto rows_of = [&](int n, int& uv0, int& uv1) {
+    const int c = lane + 64 * n;
+    const bool cv = c < G::NCHUNK;
+    const int cc = cv ? c : 0;
+    const int r0 = (16 * cc) / S, l0 = 16 * cc - S * r0;
+    uv0 = cv ? uvt[wave][r0] : 0;
+    uv1 = (cv && l0 + 16 > S) ? uvt[wave][r0 + 1] : 0;
+  };
+  uint32_t cbits = 0;
+#pragma unroll
+  for (int n = 0; n < NCL; ++n) {
+    int uv0, uv1;
+    rows_of(n, uv0, uv1);
+    cbits |= ((uv0 | uv1) != 0 ? 1u : 0u) << n;
+  }
+  int total = 0;  // wave-uniform
+#pragma unroll 1
+  for (int n = 0; n < NCL; ++n) {
+    const bool cand = (cbits >> n) & 1u;
+    const unsigned long long m = __ballot(cand);
+    const int cnt = __builtin_popcountll(m);
+    if (total + cnt > QCAP) {
+      dense_pass(total);
+      total = 0;
+    }
+    const int slot = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
+    if (cand) {
+      int uv0, uv1;
+      rows_of(n, uv0, uv1);
+      qm[wave][slot] = int4{lane + 64 * n, uv0, uv1, 0};
+    }
+    total += cnt;
+  }
+  dense_pass(total);
+  // ---- the game's nnz and flags ----
+  delta = wave_sum(delta);
+  const bool wovf = __ballot(ovf != 0) != 0;
+  if (lane == 0 && live) {
+    const int n = nnz_in + delta;
+    nnz[g] = n;
+    a.done[g] = n == 0 ? 1 : 0;
+    if (a.overflow && wovf) a.overflow[g] = 1;
+  }
+}
 
 // =============================================================================================
 // S = 9 single step (3x3 matrix multiplication), wavefront-local: four games per wavefront, a team of 16 lanes per

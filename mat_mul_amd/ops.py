@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import TG_MAX_ACTIONS, TG_MAX_S, TG_MAX_VALUES, TensorGameError, call
 
 __all__ = [
-    "step", "copy_states", "prepare_step", "step_many", "step_stream", "step_stream_layout", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
+    "step", "step_tracked", "copy_states", "prepare_step", "step_many", "step_stream", "step_stream_layout", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
     "gen_demos", "sample_basis", "change_basis", "as_tokens", "categorical_thresholds",
     "alloc_states", "alloc_ring", "emit_frames", "step_emit", "state_hash", "slice_rank", "alloc_seen_table", "seen",
 ]
@@ -179,6 +179,25 @@ def step_many(state, actions, out=None, done_step=None, overflow=None, shift: in
         call("tg_step_many_i8", _ptr(state), _ptr(out), _ptr(actions), _ptr(done_step), _ptr(overflow),
              B, S, K, stride, int(shift), _stream(dev))
     return out, done_step
+
+
+def step_tracked(state, actions, nnz, done=None, overflow=None, shift: int = 1):
+    """The in-place step that reads only what the action touches: ``nnz`` int32 (B,) carries the exact number of non-zero
+    entries per game (``done(state)[1]`` computes it) and is updated; ``done[b] = (nnz[b] == 0)``.  Same state, done and
+    overflow as ``step(state, actions, out=state)``.  Returns (state, done)."""
+    B, S, stride = _state_layout(state, "state")
+    dev = state.device
+    actions = _tokens(actions, (B,), S, dev, "actions")
+    if nnz.dtype != torch.int32 or tuple(nnz.shape) != (B,) or not nnz.is_contiguous() or nnz.device != dev:
+        raise TensorGameError("step_tracked", -1, f"nnz must be a contiguous int32 ({B},) tensor on {dev}")
+    if done is None:
+        done = torch.empty((B,), dtype=torch.uint8, device=dev)
+    done = _flag(done, (B,), torch.uint8, dev, "done")
+    overflow = _flag(overflow, (B,), torch.uint8, dev, "overflow")
+    with torch.cuda.device(dev):
+        call("tg_step_tracked_i8", _ptr(state), _ptr(actions), _ptr(nnz), _ptr(done), _ptr(overflow), B, S, stride, int(shift),
+             _stream(dev))
+    return state, done
 
 
 def step_stream_layout(B: int, S: int, device=None) -> Tuple[int, int]:

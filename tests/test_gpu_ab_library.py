@@ -81,6 +81,21 @@ for S, B in [(16, 1), (16, 3), (16, 131), (25, 2), (25, 37), (9, 1), (9, 70), (4
                 assert np.array_equal(host(out), want), (S, B, case, shift, inplace)
                 assert np.array_equal(host(done), want_done) and np.array_equal(host(ovf), want_ovf), (S, B, case, shift, inplace)
                 assert inplace or np.array_equal(host(t), st)
+# the tracked step: both of its S = 25 kernels at a small batch (TG_TRACKED_SPARSE / TG_TRACKED_FULL pick one)
+for S, B in [(25, 9), (16, 5)]:
+    rng = np.random.default_rng(S + B)
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    t = padded(st)
+    _, nnz = ops.done(t, want_nnz=True)
+    cur = st
+    for k in range(3):
+        ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)).astype(np.int8)
+        if k == 1:
+            ac[::2] = rng.integers(-100, 100, size=ac[::2].shape)
+        cur, want_done, _ = O.step_i8(cur, ac)
+        _, done = ops.step_tracked(t, dev(ac), nnz)
+        assert np.array_equal(host(t), cur) and np.array_equal(host(done), want_done), (S, B, k)
+        assert np.array_equal(host(nnz), np.count_nonzero(cur.reshape(B, -1), axis=1)), (S, B, k)
 print("STEP_OK")
 '''
 
@@ -102,7 +117,7 @@ def test_ab_switch_paths_stay_exact(env_name, tmp_path):
 
 @pytest.mark.parametrize("env_names", ["TG_S16_LINES", "TG_S16_NT_LOADS", "TG_S25_LINES", "TG_S25_NT_LOADS", "TG_NO_S25_DIRECT",
                                        "TG_NO_S16_DIRECT", "TG_NO_S9_DIRECT", "TG_S4_NT_LOADS", "TG_S4_NT_LOADS TG_S4_TOKEN_WAIT",
-                                       "TG_S16_NO_DIGITS", "TG_S16_LINES TG_S16_NO_DIGITS", "TG_S16_NT_LOADS TG_S16_NO_DIGITS",
+                                       "TG_TRACKED_SPARSE", "TG_TRACKED_FULL", "TG_S16_NO_DIGITS", "TG_S16_LINES TG_S16_NO_DIGITS", "TG_S16_NT_LOADS TG_S16_NO_DIGITS",
                                        "TG_S4_NO_DIGITS", "TG_S4_NT_LOADS TG_S4_NO_DIGITS", "TG_S4_NT_LOADS TG_S4_TOKEN_WAIT TG_S4_NO_DIGITS"])
 def test_single_step_variants_stay_exact(env_names, tmp_path):
     """The step variants the product takes by footprint only, forced here at small batches: S=16 / S=25 with whole-line

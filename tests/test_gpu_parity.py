@@ -106,6 +106,84 @@ def test_s4_digit_form_boundaries(shift):
     assert want_ovf.any() and not want_ovf.all()
 
 
+@pytest.mark.parametrize("S,B", [(16, 1), (16, 5), (16, 70), (16, 260), (25, 1), (25, 3), (25, 37), (25, 2051), (4, 70), (9, 19), (5, 6)])
+def test_step_tracked_equals_the_full_step_and_keeps_nnz(S, B):
+    """tg_step_tracked_i8: the in-place step that loads only the rows the action touches, with the number of non-zero
+    entries carried per game.  State, done and overflow must equal tg_step_i8's (hence the oracle's), nnz the count of
+    non-zero entries of the new state -- over several steps of one rollout (the count is carried), sparse and dense
+    factors (more candidates than a queue batch holds), wide tokens (32-bit redo, wrapped bytes, overflow flag), null
+    actions, states at the int8 edge, three shifts.  S = 16 / 25 take the sparse kernels (S = 25 from 2 048 games on; fewer:
+    the full step's kernel with the count), every other S the full step + tg_done_i8 inside the call."""
+    rng = np.random.default_rng(7 * S + B)
+    for case, shift in (("sparse", 1), ("dense", 1), ("wide", 1), ("wide", -2), ("edge", 1), ("null", 2), ("sparse", 3)):
+        st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+        if case == "edge":
+            st = rng.choice([-128, 127, 0, 1], size=st.shape).astype(np.int8)
+        t = padded(st)
+        _, nnz = ops.done(t, want_nnz=True)
+        assert np.array_equal(host(nnz), np.count_nonzero(st.reshape(B, -1), axis=1))
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        cur, want_ovf = st, np.zeros(B, dtype=np.uint8)
+        for k in range(3):
+            ac = (rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)) + (shift - 1)).astype(np.int8)
+            if case == "dense":
+                ac = (rng.integers(0, 3, size=(B, 3 * S)) + (shift - 1)).astype(np.int8)
+            if case == "wide":
+                ac[::2] = rng.integers(-128, 128, size=ac[::2].shape)
+            if case == "null":
+                ac[:, :S] = shift                                               # u == 0: nothing changes
+            cur, want_done, o = O.step_i8(cur, ac, shift=shift)
+            want_ovf |= o
+            _, done = ops.step_tracked(t, dev(ac), nnz, overflow=ovf, shift=shift)
+            assert np.array_equal(host(t), cur), (S, B, case, shift, k)
+            assert np.array_equal(host(done), want_done) and np.array_equal(host(ovf), want_ovf), (S, B, case, shift, k)
+            assert np.array_equal(host(nnz), np.count_nonzero(cur.reshape(B, -1), axis=1)), (S, B, case, shift, k)
+
+
+def test_env_track_nnz_matches_the_plain_env():
+    """TensorGameEnv(track_nnz=True) steps with the tracked kernel and serves nnz() from the carried count: same states,
+    done flags and counts as the plain env over a rollout, also through graph_stepper and after step_many."""
+    rng = np.random.default_rng(5)
+    for S, B in [(16, 40), (25, 6), (4, 33)]:
+        st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+        a, b = TensorGameEnv(B, S, DEV), TensorGameEnv(B, S, DEV, track_nnz=True)
+        a.reset(dev(st))
+        b.reset(dev(st))
+        assert torch.equal(a.nnz(), b.nnz())
+        for k in range(4):
+            ac = dev(rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)).astype(np.int8))
+            sa, da = a.step(ac)
+            sb, db = b.step(ac)
+            assert torch.equal(sa, sb) and torch.equal(da, db) and torch.equal(a.nnz(), b.nnz()), (S, k)
+        tokens = torch.zeros((B, 3 * S), dtype=torch.int8, device=DEV)
+        stepper = b.graph_stepper(tokens)
+        for k in range(3):
+            ac = dev(rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)).astype(np.int8))
+            tokens.copy_(ac)
+            a.step(ac)
+            stepper()
+            torch.cuda.synchronize()
+            assert torch.equal(a.state, b.state) and torch.equal(a.done, b.done) and torch.equal(a.nnz(), b.nnz()), (S, k)
+        many = dev(rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3, 3 * S)).astype(np.int8))
+        a.step_many(many)
+        b.step_many(many)
+        assert torch.equal(a.state, b.state) and torch.equal(a.nnz(), b.nnz())
+    with pytest.raises(mat_mul_amd.TensorGameError):
+        TensorGameEnv(4, 4, DEV, dim_t=2, track_nnz=True)
+
+
+def test_step_tracked_replays_a_demo_to_zero():
+    """BASELINE config 5's shape at a size the oracle is not needed for: generate, then replay the demo's own actions with
+    the tracked step -- every game ends all zero with nnz = 0 and done = 1 exactly at the last action."""
+    for S, B, R in [(25, 4096, 12), (16, 16384, 10)]:
+        tok, tgt = ops.gen_demos(B, S, R, DEV, seed=9)
+        _, nnz = ops.done(tgt, want_nnz=True)
+        done = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        for k in reversed(range(R)):
+            ops.step_tracked(tgt, tok[:, k].contiguous(), nnz, done=done)
+        assert not bool(tgt.any()) and not bool(nnz.any()) and bool(done.all()), (S, B)
+
+
 def test_strassen_dataset_448_golden(golden):
     g = golden("strassen")
     st = padded(g["ds_states"])
