@@ -58,6 +58,21 @@ for c in range(cases):
             ok = ok and np.array_equal(out.cpu().numpy(), want) and np.array_equal(done.cpu().numpy(), wdone)
             ok = ok and np.array_equal(ovf.cpu().numpy(), wovf)
             ok = ok and (inplace or np.array_equal(t.cpu().numpy(), st))
+    # the tracked step (nnz carried; S = 16 / 25: the sparse kernels, forced for every batch under TG_TRACKED_SPARSE) on the
+    # same material, two steps of one rollout
+    for layout in ("padded", "packed"):
+        t = padded(st) if layout == "padded" else torch.from_numpy(st).to(DEV)
+        _, nnz = ops.done(t, want_nnz=True)
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        cur, wo2 = st, np.zeros(B, np.uint8)
+        for k in range(2):
+            tk = np.roll(tok, k, axis=0)
+            cur, d2, o2 = O.step_i8(cur, tk, shift=shift)
+            wo2 |= o2
+            _, done = ops.step_tracked(t, torch.from_numpy(tk).to(DEV), nnz, overflow=ovf, shift=shift)
+            ok = ok and np.array_equal(t.cpu().numpy(), cur) and np.array_equal(done.cpu().numpy(), d2)
+            ok = ok and np.array_equal(nnz.cpu().numpy(), np.count_nonzero(cur.reshape(B, -1), axis=1))
+        ok = ok and np.array_equal(ovf.cpu().numpy(), wo2)
     if S in (4, 16) and abs(shift) <= 127:  # the streamed stepper (|shift| <= 127 only): K steps of the same kind
         K = int(rng.integers(1, 6))
         toks = np.stack([np.roll(tok, k, axis=0) for k in range(K)])
