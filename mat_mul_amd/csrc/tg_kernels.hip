@@ -613,7 +613,7 @@ __global__ __launch_bounds__(kBlock) void s4_step_emit_kernel(StepEmitArgs a) {
   uint32_t nz = 0;
   int ovf = 0;
   // u and v exchanged: the lane's constant is -v_q, dword d takes u_d
-  const uint4 nw = s4_step_slice(uint4{x[0], x[1], x[2], x[3]}, dv, du, dw, q, a.shift, nz, ovf);
+  const uint4 nw = s4_step_tiered(uint4{x[0], x[1], x[2], x[3]}, dv, du, dw, q, a.shift, s4_digits_limit(a.shift), nz, ovf);
   const uint32_t y[4] = {nw.x, nw.y, nw.z, nw.w};
   // (`live` is uniform over a team, so the pair exchange of the 16-bit path stays inside the active lanes)
   OutT* const out = static_cast<OutT*>(a.out) + g * (a.T * 64);
