@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 2 /* 2: the generator draws 16-bit uniforms (8 per Philox block); tg_copy_i8 */
+#define TG_ABI_VERSION 3 /* 2: the generator draws 16-bit uniforms (8 per Philox block); tg_copy_i8.  3 (additions only, round 3):
+                          * tg_step_tracked_i8, tg_step_emit, tg_expand_keyed_i8, tg_seen_u64 */
 #define TG_MAX_S 32
 #define TG_MAX_VALUES 8 /* categories of the factor distribution */
 

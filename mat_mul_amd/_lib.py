@@ -13,7 +13,7 @@ AB_VARIANT = _VARIANT in ("ab", "stamps")
 LIB_PATH = Path(__file__).resolve().parent / "lib" / {"ab": "libtensorgame_ab.so", "stamps": "libtensorgame_stamps.so"}.get(
     _VARIANT, "libtensorgame.so")
 
-TG_ABI_VERSION = 2
+TG_ABI_VERSION = 3
 TG_MAX_S = 32
 TG_MAX_VALUES = 8
 TG_MAX_ACTIONS = 4096

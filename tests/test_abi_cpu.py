@@ -27,7 +27,7 @@ def test_header_symbols_all_exported():
     lib = C.CDLL(str(_lib.LIB_PATH))
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.tg_abi_version() == 2
+    assert lib.tg_abi_version() == 3
     # the A/B variant exports exactly the same entries (it differs only by its environment switches)
     from mat_mul_amd import build
     assert declared_symbols(ab=True) == syms
