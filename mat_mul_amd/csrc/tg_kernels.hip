@@ -934,47 +934,136 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
     pk[n] = *reinterpret_cast<const uint4*>(a.state + g[n] * a.stride + 16 * q);
   }
   const int dig_limit = s4_digits_limit(a.shift);
-  for (int k = 0; k < a.K; ++k) {
-    if (a.ready) {  // relaxed agent-scope poll (bypasses this CU's L1), one address for the wavefront
-      uint32_t spins = 0;
-      while (__hip_atomic_load(a.ready + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        if (++spins >= a.spin_limit) {  // wave-uniform (same address, same value in every lane)
-          if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return;
-        }
-        __builtin_amdgcn_s_sleep(2);
+  // The step's chain, in BLOCKS (round 3).  It used to be, per step: poll ready[k] -> the tokens -> arithmetic ->
+  // write-through drain -> progress: three memory round trips in a row.  Now a wavefront takes as many steps at once as
+  // it has already SEEN released, up to D: the tokens of a block's D steps are requested together, right behind the
+  // stores of the previous block (so that block's drain and this block's token round trip overlap), and a poll of the
+  // NEXT block's D ready words travels with them.  One round trip per block instead of three per step; progress is
+  // published per block.  A producer that releases block k + 1 only after progress[k] (the interactive case) is seen
+  // as "one step released": blocks of one, progress per step, the serial order drain -> publish -> spin -> tokens.
+  // Invariant: the tokens of step j are requested only after ready[j] was observed set (by an earlier poll).
+  // The requests are asm loads with counted waits: vmcnt counts loads and stores together in issue order, so "all but
+  // the loads behind them" is exactly the previous block's stores; hipcc's own bookkeeping would drain everything,
+  // progress store included, at the loop header.  No asm load is in flight across the loop's back edge.
+  // One dword per lane and step (lane q holds dword min(q, 2) of its game's twelve bytes; s4_team_token_bcast).
+  constexpr int D = NG == 1 ? 8 : (NG == 2 ? 4 : 2);
+  uint32_t tk[D][NG], pollv = 0u;
+  const uint32_t toff0 = static_cast<uint32_t>(g0 + lg) * 12u + 4u * static_cast<uint32_t>(q < 3 ? q : 2);
+  const uint32_t toff_last = static_cast<uint32_t>(a.B - 1) * 12u + 4u * static_cast<uint32_t>(q < 3 ? q : 2);
+  // poll of ready[kp + lane], lane < D (with_poll), then the tokens of steps kb .. kb + D - 1 (steps beyond K - 1 repeat
+  // the last one; what lies beyond the released steps is loaded and never looked at): sc1 loads, the producer is another agent
+  auto request = [&](int kb, int kp, bool with_poll) {
+    if (with_poll) {
+      const uint32_t* rp = a.ready + kp;
+      const uint32_t poff = (lane < D && kp + lane < a.K) ? 4u * lane : 0u;
+      asm volatile("global_load_dword %0, %1, %2 sc1" : "=&v"(pollv) : "v"(poff), "s"(rp) : "memory");
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int kd = kb + d < a.K ? kb + d : a.K - 1;
+      const int8_t* blk = a.actions + static_cast<int64_t>(kd) * a.B * 12;
+#pragma unroll
+      for (int n = 0; n < NG; ++n) {
+        uint32_t off = toff0 + 192u * n;
+        off = off < toff_last ? off : toff_last;  // dead lanes shadow the last game
+        asm volatile("global_load_dword %0, %1, %2 sc1" : "=&v"(tk[d][n]) : "v"(off), "s"(blk) : "memory");
       }
     }
-    const int8_t* blk = a.actions + static_cast<int64_t>(k) * a.B * 12;
-    uint8_t* dn = a.done + static_cast<int64_t>(k) * a.B;
-    (void)dn;
+  };
+  auto arrived = [&]() {  // after the wait that covers them: from here on the registers hold the loaded values
 #pragma unroll
-    for (int n = 0; n < NG; ++n) {
-      const int* tp = reinterpret_cast<const int*>(blk + g[n] * 12);
-      // sc1 loads: the tokens were written by another agent after this CU may have cached the lines (ring reuse)
-      const uint32_t du = static_cast<uint32_t>(__hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      const uint32_t dv = static_cast<uint32_t>(__hip_atomic_load(tp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      const uint32_t dw = static_cast<uint32_t>(__hip_atomic_load(tp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      uint32_t nz = 0;
-      int ovf = 0;
-      pk[n] = s4_step_tiered(pk[n], du, dv, dw, q, a.shift, dig_limit, nz, ovf);
-      const bool any_nz = team_any<4>(nz != 0);
-      const bool any_ovf = team_any<4>((ovf & ~255) != 0);
-      if (live[n]) {  // write-through (sc1) stores: visible to other agents once this wavefront's vmcnt drains
-        typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
-        __builtin_amdgcn_raw_buffer_store_b128(tg_u32x4{pk[n].x, pk[n].y, pk[n].z, pk[n].w}, srs,
-                                               static_cast<int>(g[n] * a.stride) + 16 * q, 0, 16);
-        if (q == 0) {
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int n = 0; n < NG; ++n) asm volatile("" : "+v"(tk[d][n]));
+    asm volatile("" : "+v"(pollv));
+  };
+  // how many of ready[kp], ready[kp + 1], ... are set without a gap, given lane's word in v (lanes < D, kp + lane < K)
+  auto released = [&](uint32_t v, int kp) {
+    const unsigned long long m = __ballot(lane < D && kp + lane < a.K && v != 0);
+    return static_cast<int>(__builtin_ctzll(~m));  // uniform, <= D
+  };
+  auto poll_now = [&](int kp) {  // relaxed agent-scope loads (bypass this CU's L1)
+    const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    return released(v, kp);
+  };
+  auto wait_released = [&](int kp) {  // every spin is bounded; 0 = gave up
+    uint32_t spins = 0;
+    for (;;) {
+      const int n = poll_now(kp);
+      if (n) return n;
+      if (++spins >= a.spin_limit) {
+        if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  };
+  // (the state is in its registers before the first asm load: hipcc waits for its own loads with vmcnt(0) wherever it
+  // thinks one may still be pending -- inside the loop that would be every block)
+#pragma unroll
+  for (int n = 0; n < NG; ++n) asm volatile("" : "+v"(pk[n].x), "+v"(pk[n].y), "+v"(pk[n].z), "+v"(pk[n].w));
+  int kb = 0;                                         // first step of the block (uniform)
+  int nb = a.ready ? wait_released(0) : (a.K < D ? a.K : D);  // its steps: released, not yet requested
+  if (nb == 0) return;
+  bool fresh = true;  // nothing stored since the last publish (the first block; after the serial order below)
+  for (;;) {
+    const bool with_poll = a.ready && kb + nb < a.K;  // uniform
+    request(kb, kb + nb, with_poll);
+    if (a.progress && !fresh) {  // the previous block's stores have left: publish its last step
+      if (with_poll) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NG + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NG) : "memory");
+      if (lane == 0) __hip_atomic_store(a.progress + unit, static_cast<uint32_t>(kb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the tokens are in; only that progress store may be under way
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    arrived();
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (d >= nb) break;  // uniform
+      const int k = kb + d;
+#pragma unroll
+      for (int n = 0; n < NG; ++n) {
+        uint32_t du, dv, dw;
+        s4_team_token_bcast(tk[d][n], du, dv, dw);
+        uint32_t nz = 0;
+        int ovf = 0;
+        pk[n] = s4_step_tiered(pk[n], du, dv, dw, q, a.shift, dig_limit, nz, ovf);
+        const bool any_nz = team_any<4>(nz != 0);
+        const bool any_ovf = team_any<4>((ovf & ~255) != 0);
+        if (live[n] && q == 0) {  // write-through (sc1) stores: visible to other agents once this wavefront's vmcnt drains
           __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(any_nz ? 0 : 1), drs,
                                                static_cast<int>(static_cast<int64_t>(k) * a.B + g[n]), 0, 16);
           if (a.overflow && any_ovf) a.overflow[g[n]] = 1;
         }
       }
     }
-    if (a.progress) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores of step k have left
-      if (lane == 0) __hip_atomic_store(a.progress + unit, static_cast<uint32_t>(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the state leaves once per block, as whole 64-byte games (16 games of a wavefront: 1 KiB in a row): nobody may
+    // look at it before the block's progress word, and a block of one -- the interactive case -- is the old per-step store
+#pragma unroll
+    for (int n = 0; n < NG; ++n) {
+      typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
+      if (live[n])
+        __builtin_amdgcn_raw_buffer_store_b128(tg_u32x4{pk[n].x, pk[n].y, pk[n].z, pk[n].w}, srs,
+                                               static_cast<int>(g[n] * a.stride) + 16 * q, 0, 16);
     }
+    kb += nb;
+    fresh = false;
+    if (kb >= a.K) break;
+    nb = a.ready ? released(pollv, kb) : (a.K - kb < D ? a.K - kb : D);
+    if (nb == 0) {  // nothing released beyond this block yet: the serial order
+      if (a.progress) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(a.progress + unit, static_cast<uint32_t>(kb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      fresh = true;
+      nb = wait_released(kb);
+      if (nb == 0) return;
+    }
+  }
+  if (a.progress) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's last stores have left
+    if (lane == 0) __hip_atomic_store(a.progress + unit, static_cast<uint32_t>(a.K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1298,143 +1387,209 @@ __global__ __launch_bounds__(kBlock, 8) void s16_tracked_kernel(ApplyArgs a, int
 }
 
 // =============================================================================================
-// tg_step_stream_i8, S = 16: one wavefront per game, the game's 4 KiB live in 16 VGPRs per lane for all K steps (lane
-// (r, j) owns rows (i = r + 4 n, j), as in s16_step_kernel).  A step reads 48 token bytes and writes through only the
-// rows the action changed (9 % with the reference's vocabulary) plus `done`: the launch-per-step kernel re-reads
-// 32 MiB per step at BASELINE config 3, this one moves ~3 MB.  8192 games = 32 wavefronts per CU on 256 CUs: all
-// resident at <= 64 VGPRs (__launch_bounds__(256, 8)).
-// With eight wavefronts per SIMD a step is bound by instruction issue, so -- as in s16_step_kernel -- the arithmetic is
-// done only on the rows the action touches: candidates go through the wavefront's 64-entry queue in LDS, one dense pass
-// computes and stores them, and the results return through the queue to the registers of their owners.
+// tg_step_stream_i8, S = 16: one wavefront per game, resident for all K steps.  A step reads 48 token bytes and writes
+// through only the rows the action changed (9 % with the reference's vocabulary) plus `done`: the launch-per-step kernel
+// re-reads 32 MiB per step at BASELINE config 3, this one moves ~3 MB.  8192 games = 32 wavefronts per CU on 256 CUs:
+// all resident (__launch_bounds__(256, 8), 17 KiB of LDS per workgroup).
+// Round 3: the game's 4 KiB live in LDS, not in 16 VGPRs per lane, and the stepper is the TRACKED step
+// (s16_tracked_kernel) against that image: the candidate rows' indices are compacted into the wavefront's 64-entry queue,
+// lane k takes entry k -- row from LDS, digit form (packed int16 form behind it), row back to LDS and written through --
+// and `done` comes from the carried count of non-zero entries (counted once at the start, then the changed rows' bytes
+// before and after), so no instruction touches the 91 % of the state a step leaves alone.  (The register-resident form
+// copied candidate rows into the queue and back and OR-ed all sixteen registers per step; at 64 VGPRs it had no room for
+// the pipelined token requests below.)  A game with more than 64 candidate rows (dense factors) takes four rounds, round n
+// the rows i = r + 4 n (at most 64 by construction).
 // =============================================================================================
 __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  constexpr int QCAP = 64;
-  __shared__ __attribute__((aligned(16))) uint4 qd[kBlock / 64][QCAP];
-  __shared__ __attribute__((aligned(8))) int2 qm[kBlock / 64][QCAP];
+  constexpr int NW = kBlock / 64, QCAP = 64;
+  __shared__ __attribute__((aligned(16))) uint4 img[NW][256];  // row (i, j) = chunk 16 i + j
+  __shared__ int qm[NW][QCAP];                                 // (-u_i v_j) << 8 | chunk
+  constexpr int D = 8;                                         // steps per block (below)
+  __shared__ __attribute__((aligned(16))) uint32_t tokbuf[NW][D][12];  // the block's tokens: 48 bytes per step
   const int lane = threadIdx.x & 63;
-  // the game index is wave-uniform; say so (readfirstlane), or hipcc wraps every access through the per-game token
-  // descriptor in a waterfall loop
+  // the game index is wave-uniform; say so (readfirstlane): its token and flag addresses stay on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int64_t g = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave;
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * NW + wave;
   if (g >= a.B) return;
   const int r = lane >> 4;
   const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.state, 0, static_cast<int>(a.B * a.stride), 0x00027000);
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(a.done, 0, 0x7fffffff, 0x00027000);
   const int soff = static_cast<int>(g * a.stride);
-  const int8_t* const src = a.state + g * a.stride + 16 * lane;
-  // (four named chunks, not an array: see s16_step_kernel)
-  uint4 p0 = *reinterpret_cast<const uint4*>(src), p1 = *reinterpret_cast<const uint4*>(src + 1024),
-        p2 = *reinterpret_cast<const uint4*>(src + 2048), p3 = *reinterpret_cast<const uint4*>(src + 3072);
+  int nnz;  // uniform
+  {
+    const int8_t* const src = a.state + g * a.stride + 16 * lane;
+    const uint4 p0 = *reinterpret_cast<const uint4*>(src), p1 = *reinterpret_cast<const uint4*>(src + 1024),
+                p2 = *reinterpret_cast<const uint4*>(src + 2048), p3 = *reinterpret_cast<const uint4*>(src + 3072);
+    img[wave][lane] = p0;
+    img[wave][lane + 64] = p1;
+    img[wave][lane + 128] = p2;
+    img[wave][lane + 192] = p3;
+    nnz = __builtin_amdgcn_readfirstlane(wave_sum(nz_bytes16(p0) + nz_bytes16(p1) + nz_bytes16(p2) + nz_bytes16(p3)));
+  }
   const uint32_t shp = (static_cast<uint32_t>(a.shift) & 0xFFFFu) | (static_cast<uint32_t>(a.shift) << 16);
   const bool wide_shift = static_cast<unsigned>(a.shift + 127) > 254u;  // uniform; factors may exceed 255
-  auto differs = [](const uint4& x, const uint4& y) { return x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w; };
-  for (int k = 0; k < a.K; ++k) {
-    if (a.ready) {
-      uint32_t spins = 0;
-      while (__hip_atomic_load(a.ready + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        if (++spins >= a.spin_limit) {
-          if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
+  const uint32_t shrep = static_cast<uint32_t>(a.shift) * 0x01010101u;
+  // The step's chain runs in BLOCKS as in s4_stream_kernel: up to D steps the wavefront has seen released are taken at
+  // once -- their tokens requested together right behind the previous block's stores, with the poll of the next block's
+  // ready words; asm loads (sc1: the producer is another agent), counted waits, nothing in flight across the back edge.
+  // ONE dword per lane and step -- lane l < 12 asks for dword l of the step's 48 token bytes -- staged through LDS once
+  // they are in, so that the steps run as a rolled loop (one copy of the code, no token registers live across it): a
+  // step reads u and w back as two uniform 16-byte reads (on to the scalar unit: they are the same for the whole
+  // wavefront) and its v_j as a byte.
+  uint32_t tk[D], pollv = 0u;
+  const uint32_t tk_off = 4u * (lane < 12 ? lane : 11);
+  auto tokens_of = [&](int k) { return a.actions + (static_cast<int64_t>(k) * a.B + g) * 48; };
+  auto request = [&](int kb, int kp, bool with_poll) {
+    if (with_poll) {
+      const uint32_t* rp = a.ready + kp;
+      const uint32_t poff = (lane < D && kp + lane < a.K) ? 4u * lane : 0u;
+      asm volatile("global_load_dword %0, %1, %2 sc1" : "=&v"(pollv) : "v"(poff), "s"(rp) : "memory");
     }
-    // the step's 48 tokens, sc1 (written by another agent): u and w as 16 bytes each, v_j as this lane's byte
-    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int8_t*>(a.actions + (static_cast<int64_t>(k) * a.B + g) * 48), 0, 48, 0x00027000);
-    const u32x4 uq = __builtin_amdgcn_raw_buffer_load_b128(trs, 0, 0, 16);
-    const u32x4 wqv = __builtin_amdgcn_raw_buffer_load_b128(trs, 32, 0, 16);
-    const int vj = static_cast<int8_t>(__builtin_amdgcn_raw_buffer_load_b8(trs, 16 + (lane & 15), 0, 16)) - a.shift;
-    auto wfetch = [&]() {
-      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(trs, 32, 0, 16);
-      return uint4{t[0], t[1], t[2], t[3]};
-    };
-    uint32_t ovf = 0;
-    // ---- candidates -> queue ----
-    int total = 0;  // uniform
-    // (the slot of a lane's candidate is recomputed from the ballot when the result comes back: the ballots live in
-    // SGPRs, four slots would be four more VGPRs of the 64 this kernel may use)
-    auto slot_of = [&](unsigned long long m, int base) {
-      return base + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
-    };
-    auto enqueue = [&](int n, const uint4& pn, uint32_t udw, int& uvn) {
-      const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(udw), 8 * r, 8);  // -(u_i), i = r + 4 n
-      uvn = ui * vj;
-      const unsigned long long m = __ballot(uvn != 0);
-      const int slot = slot_of(m, total);
-      if (uvn != 0 && slot < QCAP) {
-        qd[wave][slot] = pn;
-        qm[wave][slot] = int2{lane + 64 * n, uvn};
-      }
-      total += __builtin_popcountll(m);
-      return m;
-    };
-    int uv0, uv1, uv2, uv3;
-    const unsigned long long m0 = enqueue(0, p0, uq[0], uv0);
-    const int b1 = total;
-    const unsigned long long m1 = enqueue(1, p1, uq[1], uv1);
-    const int b2 = total;
-    const unsigned long long m2 = enqueue(2, p2, uq[2], uv2);
-    const int b3 = total;
-    const unsigned long long m3 = enqueue(3, p3, uq[3], uv3);
-    uint32_t wp[8];
-    unpack_pairs(uint4{wqv[0], wqv[1], wqv[2], wqv[3]}, wp);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
-    // a changed row is written through at once (sc1: visible to other agents once this wavefront's vmcnt drains)
-    auto put = [&](const uint4& res, int c) {
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4{res.x, res.y, res.z, res.w}, srs, soff + 16 * c, 0, 16);
+    for (int d = 0; d < D; ++d) {  // (steps beyond K - 1 repeat the last one; what lies beyond the released steps is never looked at)
+      const int8_t* tp = tokens_of(kb + d < a.K ? kb + d : a.K - 1);
+      asm volatile("global_load_dword %0, %1, %2 sc1" : "=&v"(tk[d]) : "v"(tk_off), "s"(tp) : "memory");
+    }
+  };
+  auto arrived = [&]() {
+#pragma unroll
+    for (int d = 0; d < D; ++d) asm volatile("" : "+v"(tk[d]));
+    asm volatile("" : "+v"(pollv));
+    if (lane < 12) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) tokbuf[wave][d][lane] = tk[d];
+    }
+    __builtin_amdgcn_wave_barrier();  // (LDS serves one wavefront's accesses in order)
+  };
+  auto released = [&](uint32_t v, int kp) {  // how many of ready[kp], ready[kp + 1], ... are set without a gap (<= D)
+    const unsigned long long m = __ballot(lane < D && kp + lane < a.K && v != 0);
+    return static_cast<int>(__builtin_ctzll(~m));
+  };
+  auto wait_released = [&](int kp) {  // every spin is bounded; 0 = gave up
+    uint32_t spins = 0;
+    for (;;) {
+      const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const int n = released(v, kp);
+      if (n) return n;
+      if (++spins >= a.spin_limit) {
+        if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  };
+  auto slot_of = [&](unsigned long long mm, int base) {
+    return base + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mm), 0u)));
+  };
+  // one step, its tokens in slot d of the block
+  auto step = [&](int k, int d) {
+    const uint4 u4 = *reinterpret_cast<const uint4*>(&tokbuf[wave][d][0]), w4 = *reinterpret_cast<const uint4*>(&tokbuf[wave][d][8]);
+    const uint32_t vdw = tokbuf[wave][d][4 + ((lane & 15) >> 2)];
+    const uint32_t us[4] = {static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(u4.x))),
+                            static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(u4.y))),
+                            static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(u4.z))),
+                            static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(u4.w)))};
+    const uint32_t ws[4] = {static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w4.x))),
+                            static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w4.y))),
+                            static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w4.z))),
+                            static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w4.w)))};
+    const int vj = __builtin_amdgcn_sbfe(static_cast<int>(vdw), 8 * (lane & 3), 8) - a.shift;
+    auto wfetch = [&]() { return uint4{ws[0], ws[1], ws[2], ws[3]}; };  // (the 32-bit redo only)
+    uint32_t ovf = 0;
+    // a row: digit form first (s16_chunk_digits; offered when all 48 tokens are <= 3: u and w on the scalar unit, the
+    // lanes' dwords of v by ballot), the packed int16 form with its weight pairs built off the common path for the rest
+    const uint32_t uw_or = us[0] | us[1] | us[2] | us[3] | ws[0] | ws[1] | ws[2] | ws[3];
+    const bool small = (uw_or & 0xFCFCFCFCu) == 0 && __ballot((vdw & 0xFCFCFCFCu) != 0) == 0;
+    const int dig_limit = small ? s4_digits_limit(a.shift) : -1;  // uniform
+    const uint32_t Wd[4] = {ws[0] - shrep, ws[1] - shrep, ws[2] - shrep, ws[3] - shrep};
+    auto chunk = [&](const uint4& x, int uvn, uint32_t& cnz) {
+      uint4 res;
+      if (__builtin_expect(s16_chunk_digits(x, uvn, Wd, dig_limit, res, cnz), 1)) return res;
+      uint32_t wp[8];
+      unpack_pairs(uint4{ws[0], ws[1], ws[2], ws[3]}, wp);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
+      return s16_chunk(x, uvn, wp, wfetch, a.shift, wide_shift, cnz, ovf);
     };
-    // One round when the candidates fit the queue; otherwise (dense factors) four rounds, round n taking chunk n of
-    // every lane (at most 64 entries by construction) -- the same dense pass either way.
+    // ---- candidate rows (u_i v_j != 0, i = r + 4 n) -> the queue; |u_i v_j| < 2^23 (int8 tokens, |shift| <= 127) ----
+    int uv[4], total = 0;  // total: uniform
+    unsigned long long m[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(us[n]), 8 * r, 8);  // -(u_i)
+      uv[n] = ui * vj;
+      m[n] = __ballot(uv[n] != 0);
+      total += __builtin_popcountll(m[n]);
+    }
     const int rounds = total <= QCAP ? 1 : 4;  // uniform
+    int delta = 0;
+#pragma unroll 1
     for (int rd = 0; rd < rounds; ++rd) {
-      int cnt = total;
-      if (rounds == 4) {
-        const unsigned long long m = rd == 0 ? m0 : (rd == 1 ? m1 : (rd == 2 ? m2 : m3));
-        const int uvn = rd == 0 ? uv0 : (rd == 1 ? uv1 : (rd == 2 ? uv2 : uv3));
-        const uint4 pn = rd == 0 ? p0 : (rd == 1 ? p1 : (rd == 2 ? p2 : p3));
-        __builtin_amdgcn_wave_barrier();
-        if (uvn != 0) {
-          const int slot = slot_of(m, 0);
-          qd[wave][slot] = pn;
-          qm[wave][slot] = int2{lane + 64 * rd, uvn};
-        }
-        cnt = __builtin_popcountll(m);
+      int cnt = 0;  // uniform
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (rounds == 4 && n != rd) continue;
+        if (uv[n] != 0) qm[wave][slot_of(m[n], cnt)] = static_cast<int>(static_cast<uint32_t>(uv[n]) << 8) | (lane + 64 * n);
+        cnt += __builtin_popcountll(m[n]);
       }
       __builtin_amdgcn_wave_barrier();  // (LDS serves one wavefront's accesses in order)
       if (lane < cnt) {
-        const uint4 x = qd[wave][lane];
-        const int2 me = qm[wave][lane];
+        const int me = qm[wave][lane];
+        const int c = me & 255;
+        const uint4 x = img[wave][c];
         uint32_t cnz;
-        const uint4 res = s16_chunk(x, me.y, wp, wfetch, a.shift, wide_shift, cnz, ovf);
-        if (differs(res, x)) put(res, me.x);
-        qd[wave][lane] = res;  // back to the owner's registers
+        const uint4 res = chunk(x, me >> 8, cnz);
+        if (res.x != x.x || res.y != x.y || res.z != x.z || res.w != x.w) {
+          // a changed row is written through at once (sc1: visible to other agents once this wavefront's vmcnt drains)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{res.x, res.y, res.z, res.w}, srs, soff + 16 * c, 0, 16);
+          img[wave][c] = res;
+          delta += nz_bytes16(res) - nz_bytes16(x);
+        }
       }
       __builtin_amdgcn_wave_barrier();
-      if (rounds == 1) {
-        if (uv0 != 0) p0 = qd[wave][slot_of(m0, 0)];
-        if (uv1 != 0) p1 = qd[wave][slot_of(m1, b1)];
-        if (uv2 != 0) p2 = qd[wave][slot_of(m2, b2)];
-        if (uv3 != 0) p3 = qd[wave][slot_of(m3, b3)];
-      } else {
-        if (rd == 0 && uv0 != 0) p0 = qd[wave][slot_of(m0, 0)];
-        if (rd == 1 && uv1 != 0) p1 = qd[wave][slot_of(m1, 0)];
-        if (rd == 2 && uv2 != 0) p2 = qd[wave][slot_of(m2, 0)];
-        if (rd == 3 && uv3 != 0) p3 = qd[wave][slot_of(m3, 0)];
-      }
     }
-    const uint32_t nz = p0.x | p0.y | p0.z | p0.w | p1.x | p1.y | p1.z | p1.w | p2.x | p2.y | p2.z | p2.w | p3.x | p3.y | p3.z | p3.w;
-    const bool any_nz = __ballot(nz != 0) != 0;
+    nnz += __builtin_amdgcn_readfirstlane(wave_sum(delta));
     if (lane == 0)
-      __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(any_nz ? 0 : 1), drs,
+      __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(nnz == 0 ? 1 : 0), drs,
                                            static_cast<int>(static_cast<int64_t>(k) * a.B + g), 0, 16);
     if (__builtin_expect(ovf != 0, 0) && a.overflow) a.overflow[g] = 1;
-    if (a.progress) {
+  };
+  int kb = 0;                                                  // first step of the block (uniform)
+  int nb = a.ready ? wait_released(0) : (a.K < D ? a.K : D);   // its steps: released, not yet requested
+  if (nb == 0) return;
+  bool fresh = true;  // nothing stored since the last publish
+  for (;;) {
+    const bool with_poll = a.ready && kb + nb < a.K;  // uniform
+    request(kb, kb + nb, with_poll);
+    if (a.progress && !fresh) {  // the previous block's stores have left: publish its last step
+      if (with_poll) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
+      if (lane == 0) __hip_atomic_store(a.progress + g, static_cast<uint32_t>(kb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the tokens are in; only that progress store may be under way
+    } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(a.progress + g, static_cast<uint32_t>(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    arrived();
+#pragma unroll 1
+    for (int d = 0; d < nb; ++d) step(kb + d, d);
+    kb += nb;
+    fresh = false;
+    if (kb >= a.K) break;
+    nb = a.ready ? released(pollv, kb) : (a.K - kb < D ? a.K - kb : D);
+    if (nb == 0) {  // nothing released beyond this block yet: the serial order
+      if (a.progress) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(a.progress + g, static_cast<uint32_t>(kb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      fresh = true;
+      nb = wait_released(kb);
+      if (nb == 0) return;
+    }
+  }
+  if (a.progress) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's last stores have left
+    if (lane == 0) __hip_atomic_store(a.progress + g, static_cast<uint32_t>(a.K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
