@@ -1506,8 +1506,10 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
     auto chunk = [&](const uint4& x, int uvn, uint32_t& cnz) {
       uint4 res;
       if (__builtin_expect(s16_chunk_digits(x, uvn, Wd, dig_limit, res, cnz), 1)) return res;
+      uint32_t w0 = ws[0], w1 = ws[1], w2 = ws[2], w3 = ws[3];
+      asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));  // (or hipcc builds the weight pairs on the common path)
       uint32_t wp[8];
-      unpack_pairs(uint4{ws[0], ws[1], ws[2], ws[3]}, wp);
+      unpack_pairs(uint4{w0, w1, w2, w3}, wp);
 #pragma unroll
       for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
       return s16_chunk(x, uvn, wp, wfetch, a.shift, wide_shift, cnz, ovf);
@@ -1518,21 +1520,13 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(us[n]), 8 * r, 8);  // -(u_i)
-      uv[n] = ui * vj;
+      uv[n] = __mul24(ui, vj);  // (|factor| <= 255 here: full rate, v_mul_lo_u32 is a quarter-rate instruction)
       m[n] = __ballot(uv[n] != 0);
       total += __builtin_popcountll(m[n]);
     }
-    const int rounds = total <= QCAP ? 1 : 4;  // uniform
     int delta = 0;
-#pragma unroll 1
-    for (int rd = 0; rd < rounds; ++rd) {
-      int cnt = 0;  // uniform
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        if (rounds == 4 && n != rd) continue;
-        if (uv[n] != 0) qm[wave][slot_of(m[n], cnt)] = static_cast<int>(static_cast<uint32_t>(uv[n]) << 8) | (lane + 64 * n);
-        cnt += __builtin_popcountll(m[n]);
-      }
+    // the dense pass: lane e < cnt takes queue entry e -- row from LDS, arithmetic, row back and written through
+    auto pass = [&](int cnt) {
       __builtin_amdgcn_wave_barrier();  // (LDS serves one wavefront's accesses in order)
       if (lane < cnt) {
         const int me = qm[wave][lane];
@@ -1548,6 +1542,27 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
         }
       }
       __builtin_amdgcn_wave_barrier();
+    };
+    if (__builtin_expect(total <= QCAP, 1)) {
+      int base = 0;  // uniform
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (uv[n] != 0) qm[wave][slot_of(m[n], base)] = static_cast<int>(static_cast<uint32_t>(uv[n]) << 8) | (lane + 64 * n);
+        base += __builtin_popcountll(m[n]);
+      }
+      pass(total);
+    } else {  // dense factors: four rounds, round n the rows i = r + 4 n (at most 64 by construction)
+#pragma unroll 1
+      for (int rd = 0; rd < 4; ++rd) {
+        int cnt = 0;  // uniform
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if (n != rd) continue;
+          if (uv[n] != 0) qm[wave][slot_of(m[n], 0)] = static_cast<int>(static_cast<uint32_t>(uv[n]) << 8) | (lane + 64 * n);
+          cnt = __builtin_popcountll(m[n]);
+        }
+        pass(cnt);
+      }
     }
     nnz += __builtin_amdgcn_readfirstlane(wave_sum(delta));
     if (lane == 0)

@@ -547,10 +547,10 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
   }
 }
 
-// number of non-zero bytes of a dword (v_bcnt accumulates)
+// number of non-zero bytes of a dword, accumulated: TWO instructions.  v_msad_u8 sums |a_i - b_i| over the bytes with
+// b_i != 0, and x ^ 0x01010101 differs from x by exactly one in every byte (four with the mask-and-popcount form)
 __device__ __forceinline__ int nz_bytes(uint32_t x, int acc) {
-  const uint32_t m = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-  return __builtin_popcount(m) + acc;
+  return static_cast<int>(__builtin_amdgcn_msad_u8(x ^ 0x01010101u, x, static_cast<uint32_t>(acc)));
 }
 __device__ __forceinline__ int nz_bytes16(const uint4& q) { return nz_bytes(q.x, nz_bytes(q.y, nz_bytes(q.z, nz_bytes(q.w, 0)))); }
 
