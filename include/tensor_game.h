@@ -95,21 +95,25 @@ int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* act
  * done are DEVICE memory: the stepper polls and publishes with agent-scope (sc1) accesses, which do not order against
  * a host thread writing through mapped memory.  Same results as K calls of tg_step_i8(state, state, actions[k], done[k], ...);
  * what it removes is the dependent-launch boundary between two steps (1.55 us on MI355X, more than the step itself
- * at S=4, B=65 536): the stepper stays resident, keeps every game's state in registers and per step only polls,
- * reads 12 token bytes per game and writes the new state through.
+ * at S=4, B=65 536): the stepper stays resident, keeps every game's state on chip (S = 4: registers, S = 16: LDS) and
+ * per step only reads the token bytes and writes done[k] and -- at the latest when it publishes -- the new state through.
+ * A wavefront takes all the steps it finds released at once (up to 8): with a producer that runs ahead the state and the
+ * progress word advance in blocks of steps; a producer that releases step k+1 only after progress k+1 sees every step.
  *   actions: int8 (K,B,3S), STEP-major.  ready: uint32 (K) or NULL; step k reads its block once ready[k] != 0
  *   (the producer -- a kernel or a copy on this device -- writes the block, then ready[k]; stream order or a release at
    agent scope makes the block visible first); NULL = every
  *   block is valid at launch.  done: uint8 (K,B), done[k][b] as tg_step_i8 would report after step k.
  *   progress: uint32 (n_units) or NULL; the games are owned by n_units wavefronts, unit u = games
- *   [u*games_per_unit, (u+1)*games_per_unit) (tg_step_stream_layout); once the state and done[k] of its games are
- *   visible to other agents (write-through stores, drained) unit u stores k+1 into progress[u].
+ *   [u*games_per_unit, (u+1)*games_per_unit) (tg_step_stream_layout); progress[u] = k+1 says: the state after step k
+ *   and done[0..k] of unit u's games are visible to other agents (write-through stores, drained).  The word is
+ *   non-decreasing, ends at K, and is stored before the unit waits for a ready word that is not set yet; between two
+ *   stores of it the state in memory is not defined.
  *   status: uint32 (1) or NULL, set to 1 if a wavefront gave up waiting for a ready word (bounded spin, ~1 s).
  * No wavefront ever waits for another one, so the launch itself cannot deadlock; a producer that waits for the WHOLE
  * batch before releasing the next step additionally needs every unit resident at once: at S = 4
  * tg_step_stream_layout chooses the games per wavefront so that this holds and refuses batches beyond what the
  * device keeps resident (about 4.5e5 games on the 256 CUs of an MI355X); S = 16 (one wavefront per game, the 4 KiB of
- * a game in registers) holds 32 games per CU = 8 192 on 256 CUs, beyond that the units run in rounds.  S = 4 and S = 16 in this build (TG_ERR_UNSUPPORTED otherwise), states 16-byte
+ * a game in LDS) holds 32 games per CU = 8 192 on 256 CUs, beyond that the units run in rounds.  S = 4 and S = 16 in this build (TG_ERR_UNSUPPORTED otherwise), states 16-byte
  * aligned (S = 16: actions too).  This is a separate entry with its own metric: the single-step figures of tg_step_i8
  * never include it. */
 int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8_t* overflow,

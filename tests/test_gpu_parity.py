@@ -1351,6 +1351,44 @@ def test_step_stream_waits_for_ready_words_and_times_out():
     assert int(status[0]) == 1 and np.array_equal(host(t2), two)
 
 
+@pytest.mark.parametrize("S,B,K", [(4, 300, 21), (4, 5000, 11), (16, 70, 19)])
+def test_step_stream_takes_released_steps_in_blocks(S, B, K):
+    """Round 3: a wavefront takes all the steps it finds released at once (up to 8).  Ready words pre-set with GAPS
+    (a set word behind an unset one must not be taken), the rest released in bursts of 1..9 from a second stream while the
+    stepper is resident: state, every done[k], progress and status as K single steps."""
+    rng = np.random.default_rng(S * 1000 + B + K)
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(K, B, 3 * S)).astype(np.int8)
+    want_done, cur = np.zeros((K, B), np.uint8), st.copy()
+    for k in range(K):
+        cur, want_done[k], _ = O.step_i8(cur, ac[k])
+    t, acd = padded(st), dev(ac)
+    ready = torch.zeros(K, dtype=torch.int32, device=DEV)
+    ready[:3] = 1
+    ready[4:6] = 1                                                        # behind the gap at 3: not to be taken yet
+    ready[K - 1] = 1
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    n_units, _ = ops.step_stream_layout(B, S, DEV)
+    prog = torch.zeros(n_units, dtype=torch.int32, device=DEV)
+    done = torch.zeros((K, B), dtype=torch.uint8, device=DEV)
+    torch.cuda.synchronize()
+    side, prod = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)     # (separate hardware queues: see the tests above)
+    with torch.cuda.stream(side):
+        ops.step_stream(t, acd, done=done, ready=ready, progress=prog, status=status)
+    with torch.cuda.stream(prod):
+        k = 3
+        for burst in (1, 4, 2, 9, 1, 3, 8, 8):
+            ready[k:min(K, k + burst)].fill_(1)
+            prod.synchronize()
+            k += burst
+            if k >= K:
+                break
+    side.synchronize()
+    if int(status[0]) == 1:
+        pytest.skip("producer and stepper were not scheduled concurrently (the stepper timed out as designed)")
+    assert np.array_equal(host(t), cur) and np.array_equal(host(done), want_done) and bool((prog == K).all())
+
+
 @pytest.mark.parametrize("S,B", [(4, 700), (16, 90)])
 def test_step_stream_hand_off_is_visible_while_the_kernel_runs(S, B):
     """The publish protocol end to end: a consumer (this test, on another stream) waits for progress[u] >= k on every
