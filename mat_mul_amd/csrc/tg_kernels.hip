@@ -63,7 +63,19 @@ struct ApplyArgs {
   int only_flagged;      // MANY: redo only the games whose done_step is kNeedsExact (second pass after tg_mfma.h)
   int stream_out;        // EXPAND, S = 4 / 16: the children leave by non-temporal stores (output beyond kStreamOutBytes)
   uint64_t* keys;        // EXPAND (B,nact), nullable: the 64-bit key of every child (tg_expand_keyed_i8)
+  int sweep;             // STEP, S = 16 / 25: 1 = the workgroups take the games in reverse order (sweep_index)
 };
+
+// Alternating sweeps.  A step kernel streams the whole batch through each XCD's 4 MiB L2; the next launch streams it
+// again in the same order, so what the L2 still holds -- the END of the batch -- is evicted before that launch gets
+// there: every launch reads everything from beyond L2.  With the direction alternating from launch to launch the tail
+// of one sweep is the head of the next, and whatever part of an XCD's share fits its L2 is a hit.  Workgroup b runs on
+// XCD b mod 8 (round-robin dispatch), so the order is reversed WITHIN each residue class: a game stays on its XCD.
+__device__ __forceinline__ uint32_t sweep_index(uint32_t b, uint32_t n, int reverse) {
+  if (!reverse) return b;
+  const uint32_t x = b & 7u, t = b >> 3, tx = (n - x + 7u) >> 3;  // tx blocks have residue x
+  return ((tx - 1u - t) << 3) | x;
+}
 
 // tg_step_i8 at S = 4: from this many bytes of states on a lane awaits its token before it requests its slice
 // (s4_step_kernel<.., TW>; placed by tools/step_sizes_bench.py sweeps)
@@ -428,6 +440,7 @@ struct S4StepArgs {
   uint32_t stride;  // in == out stride (tg_step_i8 has one), < 2^20
   int shift;
   int digits_limit;  // s4_digits_limit(shift), from the host (a branch in front of the loads' consumers costs a block)
+  int sweep;         // 1 = the workgroups take the games in reverse order (sweep_index); still 64 bytes of arguments
 };
 
 //   DIG: the digit form (s4_step_digits) first, the packed form for the lanes it does not cover; false only in the
@@ -435,7 +448,7 @@ struct S4StepArgs {
 template <bool NTL, bool TW, bool DIG = true>
 __global__ __launch_bounds__(kBlock) void s4_step_kernel(S4StepArgs a) {
   constexpr int GPB = kBlock / 4;  // 64 games per workgroup
-  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * GPB;
+  const int64_t g0 = static_cast<int64_t>(sweep_index(blockIdx.x, gridDim.x, a.sweep)) * GPB;
   const int nlive = static_cast<int>(min(static_cast<int64_t>(GPB), a.B - g0));
   const int lg_raw = threadIdx.x >> 2, q = threadIdx.x & 3;
   const bool live = lg_raw < nlive;
@@ -1167,7 +1180,7 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
   __shared__ __attribute__((aligned(8))) int2 qm[kBlock / 64][QCAP];    // (chunk index, -u_i v_j)
   // (the wavefront index is uniform; saying so lets the game's tokens come by scalar loads)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  int64_t g = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave;
+  int64_t g = static_cast<int64_t>(sweep_index(blockIdx.x, gridDim.x, a.sweep)) * (kBlock / 64) + wave;
   const bool live = g < a.B;
   if (!live) g = a.B - 1;
   const int8_t* tok = a.actions + g * 48;
@@ -1865,8 +1878,9 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       const int64_t bytes = B * a.in_stride;
       const bool nt = (bytes >= (96ll << 20) || TG_SWITCH("TG_S4_NT_LOADS")) && !TG_SWITCH("TG_S4_NO_NT_LOADS");
       const bool tw = nt && (bytes >= kS4TokenWaitBytes || TG_SWITCH("TG_S4_TOKEN_WAIT")) && !TG_SWITCH("TG_S4_NO_TOKEN_WAIT");
+      // (a batch that sits in the XCDs' L2s anyway -- BASELINE config 2 -- is swept in one direction)
       const S4StepArgs sa{a.in, a.out, a.actions, a.done, a.overflow, a.B, static_cast<uint32_t>(a.in_stride), a.shift,
-                          s4_digits_limit(a.shift)};
+                          s4_digits_limit(a.shift), bytes > (16ll << 20) ? a.sweep : 0};
 #ifdef TG_AB_SWITCHES
       if (TG_SWITCH("TG_S4_NO_DIGITS")) {  // the packed form alone
         if (tw) hipLaunchKernelGGL((s4_step_kernel<true, true, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, sa);
@@ -2223,6 +2237,8 @@ int tg_debug_handovers(uint64_t* count) {
 }
 const char* tg_last_error(void) { return g_err; }
 
+static std::atomic<unsigned> g_sweep{0};  // direction of the next tg_step_i8 sweep (sweep_index)
+
 int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions, uint8_t* done,
                uint8_t* overflow, int64_t B, int S, int64_t game_stride_bytes, int shift,
                tg_stream_t stream) {
@@ -2231,6 +2247,7 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
     return fail(TG_ERR_INVALID, "tg_step_i8: null pointer");
   tg::ApplyArgs a{state_in, state_out, actions, done, nullptr, nullptr, overflow, B,
                   game_stride_bytes, game_stride_bytes, S, 1, shift};
+  a.sweep = TG_SWITCH("TG_NO_SWEEP") ? 0 : static_cast<int>(g_sweep.fetch_add(1u, std::memory_order_relaxed) & 1u);
   return launch_apply<tg::STEP>("tg_step_i8", a, static_cast<hipStream_t>(stream));
 }
 

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 7) void s25_step_kernel(ApplyAr
   __shared__ __attribute__((aligned(8))) int uvt[S * S + 3];            // -u_i v_j per row (i, j), 0 behind the last
   __shared__ int dsum;                                                  // TRACK: the workgroup's nnz delta
   const int lt = threadIdx.x, lane = lt & 63, wave = lt >> 6;
-  const int64_t g = blockIdx.x;
+  const int64_t g = sweep_index(blockIdx.x, gridDim.x, a.sweep);
   const int nnz_in = (TRACK && lt == 0) ? a.done_step[g] : 0;
   if (TRACK && lt == 0) dsum = 0;  // (the barrier behind the tables orders it)
   int delta = 0;

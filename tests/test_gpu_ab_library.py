@@ -118,7 +118,7 @@ def test_ab_switch_paths_stay_exact(env_name, tmp_path):
 @pytest.mark.parametrize("env_names", ["TG_S16_LINES", "TG_S16_NT_LOADS", "TG_S25_LINES", "TG_S25_NT_LOADS", "TG_NO_S25_DIRECT",
                                        "TG_NO_S16_DIRECT", "TG_NO_S9_DIRECT", "TG_S4_NT_LOADS", "TG_S4_NT_LOADS TG_S4_TOKEN_WAIT",
                                        "TG_TRACKED_SPARSE", "TG_TRACKED_FULL", "TG_S16_NO_DIGITS", "TG_S16_LINES TG_S16_NO_DIGITS", "TG_S16_NT_LOADS TG_S16_NO_DIGITS",
-                                       "TG_S4_NO_DIGITS", "TG_S4_NT_LOADS TG_S4_NO_DIGITS", "TG_S4_NT_LOADS TG_S4_TOKEN_WAIT TG_S4_NO_DIGITS"])
+                                       "TG_S4_NO_DIGITS", "TG_S4_NT_LOADS TG_S4_NO_DIGITS", "TG_S4_NT_LOADS TG_S4_TOKEN_WAIT TG_S4_NO_DIGITS", "TG_NO_SWEEP"])
 def test_single_step_variants_stay_exact(env_names, tmp_path):
     """The step variants the product takes by footprint only, forced here at small batches: S=16 / S=25 with whole-line
     stores (from 96 MiB of states on) and non-temporal state loads on top (320 MiB .. 1.5 GiB), S=4 with non-temporal

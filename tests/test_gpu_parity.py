@@ -1274,6 +1274,27 @@ def test_bench_two_ranks_self_launched_on_one_gpu(tmp_path):
     assert out["value"] > 1e9 and 0 < out["roofline"]["frac"] <= 1.0
 
 
+# ------------------------------------------------------------------ alternating sweep direction of tg_step_i8
+@pytest.mark.parametrize("S,B", [(4, 270001), (16, 1031), (16, 5), (25, 37), (25, 1), (25, 9)])
+def test_step_is_the_same_in_both_sweep_directions(S, B):
+    """Round 3: consecutive tg_step_i8 launches take the games in alternating order (the tail of one sweep is the head of
+    the next: L2 / Infinity Cache hits); the workgroup -> game map is a permutation for every grid size, ragged last
+    workgroups included.  Four launches in a row (both directions, twice), out of place and in place."""
+    rng = np.random.default_rng(S * 7 + B)
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)).astype(np.int8)
+    st[::3] = O.action_to_tensor(ac[::3]).astype(np.int8)
+    want, want_done, _ = O.step_i8(st, ac)
+    src, acd = dev(st), dev(ac)
+    for _ in range(4):
+        out, done = ops.step(src, acd)
+        assert np.array_equal(host(out), want) and np.array_equal(host(done), want_done)
+    for _ in range(2):
+        t = padded(st)
+        _, done = ops.step(t, acd, out=t)
+        assert np.array_equal(host(t), want) and np.array_equal(host(done), want_done)
+
+
 # ------------------------------------------------------------------ tg_step_stream_i8 (K steps, one launch, actions arriving step by step)
 @pytest.mark.parametrize("S,B,K", [(4, 1, 3), (4, 16, 5), (4, 70, 9), (4, 1000, 14), (4, 4099, 6),
                                    (16, 1, 4), (16, 7, 9), (16, 130, 6), (16, 1030, 5)])
