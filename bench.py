@@ -698,7 +698,7 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
                      "us_per_launch": round(sec * 1e6, 2), "GBps": round(nbytes / sec / 1e9, 1)})
     # the streamed stepper (its own entry and metric): K steps in ONE resident launch, the state stays in registers,
     # per step poll + 12 token bytes in + state and done written through + a progress word per wavefront
-    for (s2, b2, k2, r2) in [(4, 65536, 1008, 7), (4, 131072, 504, 7), (16, 8192, 512, 8)]:
+    for (s2, b2, k2, r2) in [(4, 65536, 1008, 7), (4, 131072, 504, 7), (16, 8192, 512, 8), (25, 4096, 256, 8)]:
         tok, tgt = ops.gen_demos(b2, s2, r2, dev, seed=4)
         cyc = torch.cat([tok, tok], dim=1)
         cyc[:, r2:, :s2] = 2 - cyc[:, r2:, :s2]                  # the same terms with u negated: period 14
@@ -728,6 +728,8 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
         if s2 == 4:   # the state leaves once per block of D steps (D = 8 / 4 / 2 for 16 / 32 / more games per wavefront)
             gpw = ops.step_stream_layout(b2, s2, dev)[1]
             moved = b2 * (3 * s2 + 1) + b2 * s2 ** 3 / {16: 8, 32: 4}.get(gpw, 2)
+        elif s2 == 25:  # whole games once per block of 8 steps
+            moved = b2 * (3 * s2 + 1) + b2 * s2 ** 3 / 8
         else:
             moved = b2 * (3 * s2 + 1) + 16.0 * changed_chunks_per_launch(s2, [acts[k] for k in range(2 * r2)])
         also.append({"workload": f"STREAMED tg_step_stream_i8: S={s2} batch={b2}, K={k2} steps in ONE launch, actions "
@@ -738,7 +740,7 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
                      "frac_of_hbm_peak_moved_bytes": round(moved * k2 / sec / 1e9 / HBM_PEAK_GBS, 4),
                      "launch_per_step_us": None,
                      "note": "bytes moved per step: tokens in, done + state out (S=16: the changed 16-byte rows; S=4: the game "
-                             "once per block of released steps); the state is not re-read, it lives on chip (S=4: "
+                             "once per block of released steps); the state is not re-read, it lives on chip (S=4, S=25: "
                              "registers, S=16: LDS)"})
         del acts, dn
     # BASELINE config 5's generator (per-GPU share: 4 096 demos, S=25, R=64), with and without the change

@@ -1622,6 +1622,277 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
 }
 
 // =============================================================================================
+// tg_step_stream_i8, S = 25 (round 3): one wavefront per game with the game's 15 625 bytes in REGISTERS for all K steps --
+// 80 VGPRs of state per lane, four wavefronts per SIMD: 4 096 games (BASELINE config 5's share of one GPU) are resident at
+// once on 256 CUs (LDS could hold 2 560).  Registers cannot be indexed by a lane, so nothing is compacted: every step
+// touches all twenty 16-byte chunks of every lane -- in the digit form, with the state kept BIASED (x ^ 0x80808080) between
+// steps so that a chunk costs eight multiply-adds, four v_sad_u8 (the new L1 norm: the zero test of this step and the
+// precondition of the next, remembered as one bit per chunk) and a compare.
+// Layout (the period trick of packed_kernel): lane t < 50 owns chunks t + 50 n, n < 20 (16 * 50 = 800 = 32 rows): its
+// 16-byte window starts at byte s = 16 t mod 25 of row r0 = floor(16 t / 25) + 32 n and runs into row r0 + 1 when s > 9 --
+// s and the split are lane constants, so the two masked weight integers per dword (W0: the window's bytes in row r0, W1:
+// those in row r0 + 1) are built once per step and a chunk needs only its two products -u_i v_j, read from a per-step
+// table in LDS at a compile-time offset.  X' = X + uv0 * W0 + uv1 * W1 per dword; exact while no digit leaves [0, 255],
+// guaranteed by: all 75 tokens <= 3 and 0 <= shift <= 3 (uniform) and the chunk's L1 norm <= 127 - F^3 (per chunk: the
+// bit).  A chunk without its bit is done byte by byte in 32-bit (wrap + overflow flag) by its lane, inline.
+// Steps come in blocks, tokens staged through LDS, state written through once per block -- as in s16_stream_kernel.
+// =============================================================================================
+__global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  constexpr int NW = kBlock / 64, D = 8, NSLOT = 20, NCH = 977, TL = 50;
+  constexpr uint32_t BIAS = 0x80808080u;
+  __shared__ int uvt[NW][656];                                          // -u_i v_j per row 25 i + j; 0 from row 625 on
+  __shared__ __attribute__((aligned(4))) uint8_t wext[NW][56];          // the w tokens, periodically extended
+  __shared__ __attribute__((aligned(16))) uint32_t tokbuf[NW][D][64];   // the block's tokens: 75 bytes per step (a row per LDS-DMA)
+  __shared__ __attribute__((aligned(16))) uint32_t pollbuf[NW][64];     // the next block's ready words
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * NW + wave;
+  if (g >= a.B) return;
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.state, 0, static_cast<int>(a.B * a.stride), 0x00027000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(a.done, 0, 0x7fffffff, 0x00027000);
+  const int soff = static_cast<int>(g * a.stride);
+  const bool act = lane < TL;
+  const int ws = (16 * lane) % 25, r0l = (16 * lane) / 25, k0 = 25 - ws;  // window start, first row, bytes in that row
+  const uint32_t shrep = static_cast<uint32_t>(a.shift) * 0x01010101u;
+  const int limit = s4_digits_limit(a.shift);
+  const uint32_t actm = act ? ~0u : 0u;
+  auto l1_of = [&](const uint4& q) {
+    return static_cast<int>(__builtin_amdgcn_sad_u8(q.w, BIAS, __builtin_amdgcn_sad_u8(q.z, BIAS,
+                            __builtin_amdgcn_sad_u8(q.y, BIAS, __builtin_amdgcn_sad_u8(q.x, BIAS, 0u)))));
+  };
+  // ---- the game -> registers, biased; the padding behind byte 15 624 (chunk 976 = lane 26, slot 19) is held as zero ----
+  uint4 x[NSLOT];
+  uint32_t okbits = 0;
+  {
+    const int8_t* const src = a.state + g * a.stride;
+#pragma unroll
+    for (int n = 0; n < NSLOT; ++n) {
+      const int c = lane + TL * n;
+      uint4 q{0, 0, 0, 0};
+      if (act && c < NCH) q = *reinterpret_cast<const uint4*>(src + 16 * c);
+      if (n == NSLOT - 1 && lane == NCH - 1 - TL * (NSLOT - 1)) {
+        q.z &= 0xFFu;
+        q.w = 0;
+      }
+      x[n] = uint4{q.x ^ BIAS, q.y ^ BIAS, q.z ^ BIAS, q.w ^ BIAS};
+      okbits |= (l1_of(x[n]) <= limit ? 1u : 0u) << n;
+    }
+  }
+  // Token requests by LDS-DMA (global_load_lds_dword: lane l's dword lands at the row's base + 4 l, no VGPR destination): this
+  // kernel runs at its register limit, and a register that an asm load has yet to fill may be copied or spilled by hipcc
+  // before the data is there -- LDS cannot.  Counted waits as in the other steppers; M0 (the DMA's LDS base) is saved
+  // and restored inside the statement.
+  // The DMA moves ALIGNED dwords: a step's 75 token bytes start at any byte address A, so lane l < 20 asks for dword l of
+  // [A - (A & 3), ...) and the step reads its token i at byte (A & 3) + i of the row (actions is 4-byte aligned: nothing in
+  // front of the buffer is touched, and behind it at most the rest of the dword that holds the last token).
+  auto tokens_of = [&](int k) { return a.actions + (static_cast<int64_t>(k) * a.B + g) * 75; };
+  auto dma = [&](const void* base, uint32_t voff, const void* lds_row) {
+    const uint32_t dst = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_row));
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3 sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(dst), "v"(voff), "s"(base) : "memory");
+  };
+  const uint32_t tk_off = lane < 20 ? 4u * lane : 0u;
+  auto request = [&](int kb, int kp, bool with_poll) {
+    if (with_poll) dma(a.ready + kp, (lane < D && kp + lane < a.K) ? 4u * lane : 0u, &pollbuf[wave][0]);
+#pragma unroll 1
+    for (int d = 0; d < D; ++d) {
+      const uintptr_t A = reinterpret_cast<uintptr_t>(tokens_of(kb + d < a.K ? kb + d : a.K - 1));
+      dma(reinterpret_cast<const void*>(A & ~static_cast<uintptr_t>(3)), tk_off, &tokbuf[wave][d][0]);
+    }
+  };
+  auto arrived = [&]() { __builtin_amdgcn_wave_barrier(); };  // behind the counted wait: the rows are in LDS
+  auto released = [&](uint32_t v, int kp) {
+    const unsigned long long m = __ballot(lane < D && kp + lane < a.K && v != 0);
+    return static_cast<int>(__builtin_ctzll(~m));
+  };
+  auto wait_released = [&](int kp) {  // every spin is bounded; 0 = gave up
+    uint32_t spins = 0;
+    for (;;) {
+      const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const int n = released(v, kp);
+      if (n) return n;
+      if (++spins >= a.spin_limit) {
+        if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  };
+  // (the state is in its registers before the first asm load, or hipcc waits for it -- with vmcnt(0) -- inside the loop)
+#pragma unroll
+  for (int n = 0; n < NSLOT; ++n) asm volatile("" : "+v"(x[n].x), "+v"(x[n].y), "+v"(x[n].z), "+v"(x[n].w));
+
+  // one step, its tokens in slot d of the block
+  auto step = [&](int k, int d) {
+    const uint8_t* const tb = reinterpret_cast<const uint8_t*>(&tokbuf[wave][d][0]) + (reinterpret_cast<uintptr_t>(tokens_of(k)) & 3);
+    // ---- per-step tables: -u_i v_j for the 625 rows, the extended w, the lane's weight integers ----
+    struct __attribute__((packed)) U32 { uint32_t v; };
+    uint32_t uw[7], uw_or = 0;  // u's bytes 0..27 on the scalar unit (bytes 25..27 are v tokens)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      uw[i] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(reinterpret_cast<const U32*>(tb + 4 * i)->v)));
+      uw_or |= uw[i];
+    }
+    const int vtok = static_cast<int8_t>(tb[25 + (lane < 25 ? lane : (lane < TL ? lane - 25 : 0))]);
+    const int wtok = static_cast<int8_t>(tb[50 + lane % 25]);
+    const int vj = vtok - a.shift;
+    // are all 75 tokens <= 3?  (uniform)
+    const bool small = (uw_or & 0xFCFCFCFCu) == 0 && __ballot(((vtok | wtok) & ~3) != 0) == 0;
+#pragma unroll
+    for (int m = 0; m < 13; ++m) {  // rows 2 m (lanes 0..24) and 2 m + 1 (lanes 25..49); "row 25" gives the zeros behind the table
+      const int ua = sbyte(uw[(2 * m) >> 2], (2 * m) & 3);
+      const int ub = 2 * m + 1 < 25 ? sbyte(uw[(2 * m + 1) >> 2], (2 * m + 1) & 3) : a.shift;
+      const int ui = a.shift - (lane < 25 ? ua : ub);
+      if (act) uvt[wave][TL * m + lane] = __mul24(ui, vj);
+    }
+    if (lane < 56) wext[wave][lane] = static_cast<uint8_t>(wtok);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t W0[4], W1[4];
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+      const uint8_t* wp = &wext[wave][ws + 4 * dd];
+      const uint32_t wq = static_cast<uint32_t>(wp[0]) | (static_cast<uint32_t>(wp[1]) << 8) | (static_cast<uint32_t>(wp[2]) << 16) |
+                          (static_cast<uint32_t>(wp[3]) << 24);
+      // byte masks: the window's bytes in row r0 / in row r0 + 1 (both 0 in the idle lanes: their weights are 0)
+      const int nbr = k0 - 4 * dd;
+      const uint32_t mk0 = (nbr <= 0 ? 0u : (nbr >= 4 ? ~0u : ((1u << (8 * nbr)) - 1u))) & actm, mk1 = ~mk0 & actm;
+      W0[dd] = (wq & mk0) - (shrep & mk0);
+      W1[dd] = (wq & mk1) - (shrep & mk1);
+    }
+    uint32_t ovf = 0;
+    // a chunk byte by byte (its precondition failed, or the step's tokens are not small): exact, wrapped, flagged
+    auto slow_chunk = [&](const uint4& xb, int uv0, int uv1) {
+      uint32_t q0 = xb.x ^ BIAS, q1 = xb.y ^ BIAS, q2 = xb.z ^ BIAS, q3 = xb.w ^ BIAS;
+      if (!act) uv0 = 0, uv1 = 0;
+#pragma unroll 1
+      for (int it = 0; it < 4; ++it) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int b = 4 * it + t;
+          const int wv = static_cast<int>(static_cast<int8_t>(wext[wave][ws + b])) - a.shift;
+          const int e = sbyte(q0, t) + __mul24(b < k0 ? uv0 : uv1, wv);  // (|u_i v_j| < 2^17, |w_l| <= 255)
+          ovf |= static_cast<uint32_t>(e + 128) & ~255u;
+          o |= (static_cast<uint32_t>(e) & 255u) << (8 * t);
+        }
+        q0 = q1, q1 = q2, q2 = q3, q3 = o;  // (rotation: no register is indexed by the loop counter)
+      }
+      return uint4{q0 ^ BIAS, q1 ^ BIAS, q2 ^ BIAS, q3 ^ BIAS};
+    };
+    // X + uv0 * W0 + uv1 * W1 per dword: two v_mad_u64_u32 (full rate; hipcc picks the quarter-rate v_mul_lo_u32 here) and an
+    // add.  The first product starts from the inline constant 0, so no register PAIR has to be set up as the addend; the
+    // statements are volatile to keep the four dwords in sequence (one result pair alive at a time: the kernel has 128 VGPRs).
+    auto fast_chunk = [&](const uint4& xb, int uv0, int uv1) {
+      auto dig = [&](uint32_t xd, uint32_t w0, uint32_t w1) {
+        uint64_t r;
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0" : "=&v"(r) : "v"(uv0), "v"(w0), "v"(uv1), "v"(w1) : "vcc");
+        return xd + static_cast<uint32_t>(r);
+      };
+      uint4 o;
+      o.x = dig(xb.x, W0[0], W1[0]);
+      o.y = dig(xb.y, W0[1], W1[1]);
+      o.z = dig(xb.z, W0[2], W1[2]);
+      o.w = dig(xb.w, W0[3], W1[3]);
+      return o;
+    };
+    const uint32_t okm = small ? okbits : 0u;
+    const bool all_fast = __ballot((okm & 0xFFFFFu) != 0xFFFFFu) == 0;  // uniform
+    uint32_t newok = 0, l1tot = 0;
+    const int* const uvp = &uvt[wave][r0l];
+    // (a chunk's two products are read one chunk ahead; the scheduling fences keep hipcc from hoisting all forty reads --
+    // and with them forty registers -- to the top: the kernel has 128)
+    int nx0 = uvp[0], nx1 = uvp[1];
+    if (__builtin_expect(all_fast, 1)) {
+#pragma unroll
+      for (int n = 0; n < NSLOT; ++n) {
+        const int uv0 = nx0, uv1 = nx1;
+        if (n + 1 < NSLOT) nx0 = uvp[32 * (n + 1)], nx1 = uvp[32 * (n + 1) + 1];
+        x[n] = fast_chunk(x[n], uv0, uv1);
+        const int l1 = l1_of(x[n]);
+        l1tot += static_cast<uint32_t>(l1);
+        newok |= (l1 <= limit ? 1u : 0u) << n;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NSLOT; ++n) {
+        const int uv0 = nx0, uv1 = nx1;
+        if (n + 1 < NSLOT) nx0 = uvp[32 * (n + 1)], nx1 = uvp[32 * (n + 1) + 1];
+        if ((okm >> n) & 1u) x[n] = fast_chunk(x[n], uv0, uv1);
+        else x[n] = slow_chunk(x[n], uv0, uv1);
+        const int l1 = l1_of(x[n]);
+        l1tot += static_cast<uint32_t>(l1);
+        newok |= (l1 <= limit ? 1u : 0u) << n;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    okbits = newok;
+    const bool any_nz = __ballot(l1tot != 0) != 0;
+    if (lane == 0)
+      __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(any_nz ? 0 : 1), drs,
+                                           static_cast<int>(static_cast<int64_t>(k) * a.B + g), 0, 16);
+    if (__ballot(ovf != 0) != 0 && a.overflow && lane == 0) a.overflow[g] = 1;
+  };
+  // the game leaves once per block (write-through, sc1): whole chunks; the last one only up to byte 15 624
+  auto put_state = [&]() {
+#pragma unroll
+    for (int n = 0; n < NSLOT; ++n) {
+      const int c = lane + TL * n;
+      const u32x4 q{x[n].x ^ BIAS, x[n].y ^ BIAS, x[n].z ^ BIAS, x[n].w ^ BIAS};
+      if (n < NSLOT - 1) {
+        if (act) __builtin_amdgcn_raw_buffer_store_b128(q, srs, soff + 16 * c, 0, 16);
+      } else {
+        if (act && c < NCH - 1) __builtin_amdgcn_raw_buffer_store_b128(q, srs, soff + 16 * c, 0, 16);
+        if (c == NCH - 1) {
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{q[0], q[1]}, srs, soff + 16 * c, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(q[2]), srs, soff + 16 * c + 8, 0, 16);
+        }
+      }
+    }
+  };
+  int kb = 0;                                                  // first step of the block (uniform)
+  int nb = a.ready ? wait_released(0) : (a.K < D ? a.K : D);   // its steps: released, not yet requested
+  if (nb == 0) return;
+  bool fresh = true;  // nothing stored since the last publish
+  for (;;) {
+    const bool with_poll = a.ready && kb + nb < a.K;  // uniform
+    request(kb, kb + nb, with_poll);
+    if (a.progress && !fresh) {  // the previous block's stores have left: publish its last step
+      if (with_poll) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
+      if (lane == 0) __hip_atomic_store(a.progress + g, static_cast<uint32_t>(kb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the tokens are in; only that progress store may be under way
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    arrived();
+#pragma unroll 1
+    for (int d = 0; d < nb; ++d) step(kb + d, d);
+    put_state();
+    kb += nb;
+    fresh = false;
+    if (kb >= a.K) break;
+    nb = a.ready ? released(pollbuf[wave][lane], kb) : (a.K - kb < D ? a.K - kb : D);
+    if (nb == 0) {  // nothing released beyond this block yet: the serial order
+      if (a.progress) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(a.progress + g, static_cast<uint32_t>(kb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      fresh = true;
+      nb = wait_released(kb);
+      if (nb == 0) return;
+    }
+  }
+  if (a.progress) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's last stores have left
+    if (lane == 0) __hip_atomic_store(a.progress + g, static_cast<uint32_t>(a.K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// =============================================================================================
 // terminal check / nnz, and reset
 // =============================================================================================
 
@@ -2254,9 +2525,9 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
 /* units (wavefronts) and games per unit of tg_step_stream_i8 for a batch of B games, or a negative TG_ERR_* */
 int tg_step_stream_layout(int64_t B, int S, int64_t* n_units, int* games_per_unit) {
   if (B < 0) return fail(TG_ERR_INVALID, "tg_step_stream_layout: B < 0");
-  if (S != 4 && S != 16)
-    return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: S=%d (the streamed stepper is built for S=4 and S=16)", S);
-  if (S == 16) {  // one wavefront per game; 32 wavefronts per CU are resident at once (8192 games on 256 CUs)
+  if (S != 4 && S != 16 && S != 25)
+    return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: S=%d (the streamed stepper is built for S=4, S=16 and S=25)", S);
+  if (S == 16 || S == 25) {  // (S = 25: a wavefront per game too, 16 per CU resident: 4 096 games on 256 CUs)  // one wavefront per game; 32 wavefronts per CU are resident at once (8192 games on 256 CUs)
     if (n_units) *n_units = B;
     if (games_per_unit) *games_per_unit = 1;
     return TG_OK;
@@ -2295,7 +2566,9 @@ int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8
   int64_t units = 0;
   int gpu_ = 0;
   if (int rc = tg_step_stream_layout(B, S, &units, &gpu_)) return rc;
-  if (!aligned16(state) || game_stride_bytes % 16 != 0 || !(S == 16 ? aligned16(actions) : aligned4(actions)) ||
+  // (a single game has no stride to speak of; S = 25 reads the 16-byte chunk that holds the game's last byte: it lies inside
+  // the last game's final aligned 16 bytes, and only the game's own 9 bytes of it are ever written)
+  if (!aligned16(state) || (game_stride_bytes % 16 != 0 && B > 1) || !(S == 16 ? aligned16(actions) : aligned4(actions)) ||
       B * game_stride_bytes > 0x7fffffffLL || static_cast<int64_t>(K) * B > 0x7fffffffLL ||
       static_cast<unsigned>(shift + 127) > 254u)
     return fail(TG_ERR_UNSUPPORTED, "%s: needs 16-byte aligned states, aligned actions (4 bytes at S=4, 16 at S=16), B*stride and K*B < 2^31, |shift| <= 127", fn);
@@ -2307,6 +2580,10 @@ int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8
   (void)hipGetLastError();
   if (S == 16) {
     hipLaunchKernelGGL(tg::s16_stream_kernel, dim3(grid), dim3(tg::kBlock), 0, st, a);
+    return check_launch(fn);
+  }
+  if (S == 25) {
+    hipLaunchKernelGGL(tg::s25_stream_kernel, dim3(grid), dim3(tg::kBlock), 0, st, a);
     return check_launch(fn);
   }
   switch (gpu_ / 16) {
