@@ -1727,6 +1727,14 @@ __global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
 
   // one step, its tokens in slot d of the block
   auto step = [&](int k, int d) {
+    // (the lane constants are worked out again in every step, from a lane index hipcc cannot see through: hoisted out of
+    // the step loop -- sixteen masks and offsets -- they went to scratch, and every step waited for twenty reloads in a row)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const bool act = ln < TL;
+    const int ws = (16 * ln) % 25, r0l = (16 * ln) / 25, k0 = 25 - ws;
+    const uint32_t actm = act ? ~0u : 0u;
+    const int lane = ln;
     const uint8_t* const tb = reinterpret_cast<const uint8_t*>(&tokbuf[wave][d][0]) + (reinterpret_cast<uintptr_t>(tokens_of(k)) & 3);
     // ---- per-step tables: -u_i v_j for the 625 rows, the extended w, the lane's weight integers ----
     struct __attribute__((packed)) U32 { uint32_t v; };
