@@ -1770,10 +1770,10 @@ __global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
       W0[dd] = (wq & mk0) - (shrep & mk0);
       W1[dd] = (wq & mk1) - (shrep & mk1);
     }
-    uint32_t ovf = 0;
+    bool ovf_any = false;  // uniform (kept off the vector registers: the kernel has none to spare)
     // a chunk byte by byte (its precondition failed, or the step's tokens are not small): exact, wrapped, flagged
     auto slow_chunk = [&](const uint4& xb, int uv0, int uv1) {
-      uint32_t q0 = xb.x ^ BIAS, q1 = xb.y ^ BIAS, q2 = xb.z ^ BIAS, q3 = xb.w ^ BIAS;
+      uint32_t q0 = xb.x ^ BIAS, q1 = xb.y ^ BIAS, q2 = xb.z ^ BIAS, q3 = xb.w ^ BIAS, ovf = 0;
       if (!act) uv0 = 0, uv1 = 0;
 #pragma unroll 1
       for (int it = 0; it < 4; ++it) {
@@ -1788,11 +1788,9 @@ __global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
         }
         q0 = q1, q1 = q2, q2 = q3, q3 = o;  // (rotation: no register is indexed by the loop counter)
       }
+      ovf_any |= ovf != 0;
       return uint4{q0 ^ BIAS, q1 ^ BIAS, q2 ^ BIAS, q3 ^ BIAS};
     };
-    // X + uv0 * W0 + uv1 * W1 per dword: two v_mad_u64_u32 (full rate; hipcc picks the quarter-rate v_mul_lo_u32 here) and an
-    // add.  The first product starts from the inline constant 0, so no register PAIR has to be set up as the addend; the
-    // statements are volatile to keep the four dwords in sequence (one result pair alive at a time: the kernel has 128 VGPRs).
     auto fast_chunk = [&](const uint4& xb, int uv0, int uv1) {
       auto dig = [&](uint32_t xd, uint32_t w0, uint32_t w1) {
         uint64_t r;
@@ -1806,14 +1804,14 @@ __global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
       o.w = dig(xb.w, W0[3], W1[3]);
       return o;
     };
-    const uint32_t okm = small ? okbits : 0u;
-    const bool all_fast = __ballot((okm & 0xFFFFFu) != 0xFFFFFu) == 0;  // uniform
-    uint32_t newok = 0, l1tot = 0;
+    // does every chunk of every lane have its bit (and the step small tokens)?  (uniform)
+    const bool all_fast = small && __ballot((okbits & 0xFFFFFu) != 0xFFFFFu) == 0;
+    uint32_t l1tot = 0;
     const int* const uvp = &uvt[wave][r0l];
-    // (a chunk's two products are read one chunk ahead; the scheduling fences keep hipcc from hoisting all forty reads --
-    // and with them forty registers -- to the top: the kernel has 128)
-    int nx0 = uvp[0], nx1 = uvp[1];
+    // (the scheduling fences keep hipcc from hoisting all forty table reads of a step -- and with them forty registers -- to the
+    // top: the kernel has 128.  A chunk's bit is read before it is replaced: one register for old and new.)
     if (__builtin_expect(all_fast, 1)) {
+      int nx0 = uvp[0], nx1 = uvp[1];  // (a chunk's two products are read one chunk ahead)
 #pragma unroll
       for (int n = 0; n < NSLOT; ++n) {
         const int uv0 = nx0, uv1 = nx1;
@@ -1821,28 +1819,26 @@ __global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
         x[n] = fast_chunk(x[n], uv0, uv1);
         const int l1 = l1_of(x[n]);
         l1tot += static_cast<uint32_t>(l1);
-        newok |= (l1 <= limit ? 1u : 0u) << n;
+        okbits = l1 <= limit ? okbits : okbits & ~(1u << n);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
       for (int n = 0; n < NSLOT; ++n) {
-        const int uv0 = nx0, uv1 = nx1;
-        if (n + 1 < NSLOT) nx0 = uvp[32 * (n + 1)], nx1 = uvp[32 * (n + 1) + 1];
-        if ((okm >> n) & 1u) x[n] = fast_chunk(x[n], uv0, uv1);
+        const int uv0 = uvp[32 * n], uv1 = uvp[32 * n + 1];
+        if (small && ((okbits >> n) & 1u)) x[n] = fast_chunk(x[n], uv0, uv1);
         else x[n] = slow_chunk(x[n], uv0, uv1);
         const int l1 = l1_of(x[n]);
         l1tot += static_cast<uint32_t>(l1);
-        newok |= (l1 <= limit ? 1u : 0u) << n;
+        okbits = l1 <= limit ? okbits | (1u << n) : okbits & ~(1u << n);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    okbits = newok;
     const bool any_nz = __ballot(l1tot != 0) != 0;
     if (lane == 0)
       __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(any_nz ? 0 : 1), drs,
                                            static_cast<int>(static_cast<int64_t>(k) * a.B + g), 0, 16);
-    if (__ballot(ovf != 0) != 0 && a.overflow && lane == 0) a.overflow[g] = 1;
+    if (__ballot(ovf_any) != 0 && a.overflow && lane == 0) a.overflow[g] = 1;
   };
   // the game leaves once per block (write-through, sc1): whole chunks; the last one only up to byte 15 624
   auto put_state = [&]() {
