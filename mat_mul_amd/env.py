@@ -174,6 +174,25 @@ class TensorGameEnv:
             self.recount()
         return self.state, done_step
 
+    def step_stream(self, actions: torch.Tensor, ready=None, progress=None, status=None,
+                    done: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """K steps in ONE resident launch (``tg_step_stream_i8``; S = 4, 16, 25, dim_t == 1): actions int8 (K,B,3S) step-major,
+        consumed as ``ready[k]`` (device int32 (K), or None = all valid now) is set by a producer on the same device -- the
+        policy network choosing action k from state k (act.py:182-183).  Same states and ``done[k]`` as K calls of
+        ``step()``, without the launch boundary between them (S=4, B=65 536: 0.5 us per step against 2.3).
+        Returns (state, done (K,B)); ``self.done`` is the last step's."""
+        if self.T > 1:
+            raise TensorGameError("step_stream", -1, "the streamed stepper keeps no history; use step() when dim_t > 1")
+        if actions.dtype != torch.int8:
+            raise TensorGameError("step_stream", -1, "actions must be int8 tokens (K,B,3S), step-major (ops.as_tokens)")
+        _, dn = ops.step_stream(self.state, actions, done=done, overflow=self.overflow, ready=ready, progress=progress,
+                                status=status, shift=self.shift)
+        self.done.copy_(dn[-1])
+        self.t += actions.shape[0]
+        if self._nnz is not None:
+            self.recount()
+        return self.state, dn
+
     def expand(self, actions: torch.Tensor, want_keys: bool = False):
         """k candidate children per game (the env is not advanced).  Returns (children, done, changed[, keys])."""
         if actions.dtype != torch.int8:

@@ -1374,6 +1374,25 @@ def test_step_stream_waits_for_ready_words_and_times_out():
     assert int(status[0]) == 1 and np.array_equal(host(t2), two)
 
 
+@pytest.mark.parametrize("S", [4, 16, 25])
+def test_env_step_stream_replays_demonstrations_to_zero(S):
+    """TensorGameEnv.step_stream: R generated actions per game in one resident launch bring every target to zero, done[k]
+    as the per-step env reports it."""
+    B, R = 50, 6
+    tok, tgt = ops.gen_demos(B, S, R, DEV, seed=S)
+    env = mat_mul_amd.TensorGameEnv(B, S, device=DEV)
+    env.reset(tgt)
+    ref = mat_mul_amd.TensorGameEnv(B, S, device=DEV)
+    ref.reset(tgt)
+    acts = tok.permute(1, 0, 2).contiguous()
+    state, done = env.step_stream(acts)
+    torch.cuda.synchronize()
+    for k in range(R):
+        _, d = ref.step(acts[k])
+        assert torch.equal(done[k], d)
+    assert torch.equal(state, ref.state) and not bool(state.any()) and bool(env.done.all()) and env.t == R
+
+
 @pytest.mark.parametrize("S,B,K", [(4, 300, 21), (4, 5000, 11), (16, 70, 19), (25, 26, 19)])
 def test_step_stream_takes_released_steps_in_blocks(S, B, K):
     """Round 3: a wavefront takes all the steps it finds released at once (up to 8).  Ready words pre-set with GAPS

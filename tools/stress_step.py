@@ -73,8 +73,8 @@ for c in range(cases):
             ok = ok and np.array_equal(t.cpu().numpy(), cur) and np.array_equal(done.cpu().numpy(), d2)
             ok = ok and np.array_equal(nnz.cpu().numpy(), np.count_nonzero(cur.reshape(B, -1), axis=1))
         ok = ok and np.array_equal(ovf.cpu().numpy(), wo2)
-    if S in (4, 16) and abs(shift) <= 127:  # the streamed stepper (|shift| <= 127 only): K steps of the same kind
-        K = int(rng.integers(1, 6))
+    if S in (4, 16, 25) and abs(shift) <= 127:  # the streamed stepper (|shift| <= 127 only): K steps of the same kind
+        K = int(rng.integers(1, 21))                                                    # (blocks of up to 8 steps)
         toks = np.stack([np.roll(tok, k, axis=0) for k in range(K)])
         cur, wd, wo = st.copy(), np.zeros((K, B), np.uint8), np.zeros(B, np.uint8)
         for k in range(K):
@@ -83,10 +83,14 @@ for c in range(cases):
             wo |= o
         t = padded(st)
         ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
-        _, done = ops.step_stream(t, torch.from_numpy(toks).to(DEV), overflow=ovf, shift=shift)
+        gated = bool(c & 1)                                                             # ready words (all set) and progress words
+        ready = torch.ones(K, dtype=torch.int32, device=DEV) if gated else None
+        prog = torch.zeros(ops.step_stream_layout(B, S, DEV)[0], dtype=torch.int32, device=DEV) if gated else None
+        status = torch.zeros(1, dtype=torch.int32, device=DEV)
+        _, done = ops.step_stream(t, torch.from_numpy(toks).to(DEV), overflow=ovf, ready=ready, progress=prog, status=status, shift=shift)
         torch.cuda.synchronize()
         ok = ok and np.array_equal(t.cpu().numpy(), cur) and np.array_equal(done.cpu().numpy(), wd)
-        ok = ok and np.array_equal(ovf.cpu().numpy(), wo)
+        ok = ok and np.array_equal(ovf.cpu().numpy(), wo) and int(status[0]) == 0 and (prog is None or bool((prog == K).all()))
     # tg_expand_i8 on the same material: k children per parent (the game's own action and its neighbours')
     k = int(rng.integers(1, 9))
     ak = np.stack([np.roll(tok, j, axis=0) for j in range(k)], axis=1)
