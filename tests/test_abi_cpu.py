@@ -121,3 +121,15 @@ def test_header_is_plain_c():
     res = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Wpedantic", "-Werror", str(hdr)],
                          capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+def test_resident_steppers_never_touch_a_register_before_its_load_is_waited_for():
+    """tools/audit_pending_loads.py on the cross-compiled assembly: the s4 / s16 stream kernels issue their token loads by inline
+    asm with counted waits; between such a load and its wait nothing may read, copy or spill the destination register (the
+    compiler does not know the data is still on its way), and the kernels use no scratch.  (hipcc -S: ~30 s.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("audit_pending_loads", ROOT / "tools" / "audit_pending_loads.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    names, problems = mod.audit(mod.assembly())
+    assert len(names) == 5 and not problems, problems
