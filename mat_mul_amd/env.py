@@ -138,23 +138,31 @@ class TensorGameEnv:
             raise TensorGameError("graph_stepper", -1, f"actions must be contiguous int8 {(self.B, 3 * self.S)} on {self.device}")
         graphs = {}
         side = torch.cuda.Stream(device=self.device)
+        calls = [0]
 
         def step() -> Tuple[torch.Tensor, torch.Tensor]:
             slot = self.head
             nxt = (slot + 1) % self.T
-            g = graphs.get(slot)
+            # Two graphs per slot, captured back to back and replayed in turn: consecutive tg_step_i8 launches sweep the batch
+            # in opposite directions (the tail of one sweep is the head of the next in L2 / the Infinity Cache), and a
+            # captured launch keeps the direction it was captured with.
+            parity = calls[0] & 1
+            calls[0] += 1
+            g = graphs.get((slot, parity))
             if g is None:
                 cur = torch.cuda.current_stream(self.device)
                 side.wait_stream(cur)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):  # capture only records the launch: nothing runs here
-                    if self._nnz is not None:
-                        ops.step_tracked(self.state, actions, self._nnz, done=self.done, overflow=self.overflow, shift=self.shift)
-                    else:
-                        ops.step(self.ring[:, slot], actions, out=self.ring[:, nxt], done=self.done,
-                                 overflow=self.overflow, shift=self.shift)
+                for p in (0, 1):
+                    gp = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gp, stream=side):  # capture only records the launch: nothing runs here
+                        if self._nnz is not None:
+                            ops.step_tracked(self.state, actions, self._nnz, done=self.done, overflow=self.overflow, shift=self.shift)
+                        else:
+                            ops.step(self.ring[:, slot], actions, out=self.ring[:, nxt], done=self.done,
+                                     overflow=self.overflow, shift=self.shift)
+                    graphs[(slot, p)] = gp
                 cur.wait_stream(side)
-                graphs[slot] = g
+                g = graphs[(slot, parity)]
             g.replay()
             self.head = nxt
             self.t += 1
