@@ -398,6 +398,32 @@ __device__ __forceinline__ uint4 s4_step_tiered(const uint4& in_slice, uint32_t 
   return s4_step_slice(in_slice, du, dv, dw, q, shift, nz, ovf);
 }
 
+// The resident stepper's form of the same step: the slice stays BIASED (x ^ 0x80808080) between steps and its L1 norm is
+// carried -- the norm of the new slice is at once this step's zero test (l1 == 0) and the next step's precondition, so a step
+// is four multiply-adds and four v_sad_u8 (s4_step_tiered: four xor in, four v_sad_u8, four multiply-adds, four xor out,
+// three or).  A lane the digit form does not cover un-biases, takes s4_step_slice and biases again.
+__device__ __forceinline__ void s4_step_biased(uint4& xb, uint32_t& l1, uint32_t du, uint32_t dv, uint32_t dw, int q, int shift,
+                                               int digits_limit, int& ovf) {
+  constexpr uint32_t BIAS = 0x80808080u;
+  const uint32_t wide = (du | dv | dw) & 0xFCFCFCFCu;
+  const uint32_t nui = static_cast<uint32_t>(shift) - (__builtin_amdgcn_alignbyte(du, du, static_cast<uint32_t>(q)) & 255u);
+  const uint32_t W = dw - static_cast<uint32_t>(shift) * 0x01010101u;
+  const uint32_t G = nui * W;
+  uint32_t vj[4];
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(vj[0]) : "v"(dv), "s"(shift));
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(vj[1]) : "v"(dv), "s"(shift));
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(vj[2]) : "v"(dv), "s"(shift));
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(vj[3]) : "v"(dv), "s"(shift));
+  uint4 o{xb.x + vj[0] * G, xb.y + vj[1] * G, xb.z + vj[2] * G, xb.w + vj[3] * G};
+  if (__builtin_expect(!(wide == 0 && static_cast<int>(l1) <= digits_limit), 0)) {
+    uint32_t nz = 0;
+    const uint4 r = s4_step_slice(uint4{xb.x ^ BIAS, xb.y ^ BIAS, xb.z ^ BIAS, xb.w ^ BIAS}, du, dv, dw, q, shift, nz, ovf);
+    o = uint4{r.x ^ BIAS, r.y ^ BIAS, r.z ^ BIAS, r.w ^ BIAS};
+  }
+  xb = o;
+  l1 = __builtin_amdgcn_sad_u8(o.w, BIAS, __builtin_amdgcn_sad_u8(o.z, BIAS, __builtin_amdgcn_sad_u8(o.y, BIAS, __builtin_amdgcn_sad_u8(o.x, BIAS, 0u))));
+}
+
 // The game's 12 token bytes as three dwords (u | v | w) in every lane of its 4-lane team from ONE dword load per lane:
 // lane q loads dword min(q, 2) and the team exchanges them by DPP quad broadcasts (three v_mov_b32_dpp).  A
 // global_load_dwordx3 per lane asks the memory pipeline for 48 bytes per game where 12 are distinct; with the token
@@ -946,6 +972,14 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
     if (!live[n]) g[n] = a.B - 1;  // dead lanes shadow the last game, stores predicated off
     pk[n] = *reinterpret_cast<const uint4*>(a.state + g[n] * a.stride + 16 * q);
   }
+  // the slices stay biased for all K steps, each with its L1 norm (s4_step_biased); un-biased when they are stored
+  uint32_t l1s[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) {
+    uint32_t xb[4];
+    l1s[n] = s4_digits_pre(pk[n], xb);
+    pk[n] = uint4{xb[0], xb[1], xb[2], xb[3]};
+  }
   const int dig_limit = s4_digits_limit(a.shift);
   // The step's chain, in BLOCKS (round 3).  It used to be, per step: poll ready[k] -> the tokens -> arithmetic ->
   // write-through drain -> progress: three memory round trips in a row.  Now a wavefront takes as many steps at once as
@@ -1039,10 +1073,9 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
       for (int n = 0; n < NG; ++n) {
         uint32_t du, dv, dw;
         s4_team_token_bcast(tk[d][n], du, dv, dw);
-        uint32_t nz = 0;
         int ovf = 0;
-        pk[n] = s4_step_tiered(pk[n], du, dv, dw, q, a.shift, dig_limit, nz, ovf);
-        const bool any_nz = team_any<4>(nz != 0);
+        s4_step_biased(pk[n], l1s[n], du, dv, dw, q, a.shift, dig_limit, ovf);
+        const bool any_nz = team_any<4>(l1s[n] != 0);
         const bool any_ovf = team_any<4>((ovf & ~255) != 0);
         if (live[n] && q == 0) {  // write-through (sc1) stores: visible to other agents once this wavefront's vmcnt drains
           __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(any_nz ? 0 : 1), drs,
@@ -1057,7 +1090,8 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
     for (int n = 0; n < NG; ++n) {
       typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
       if (live[n])
-        __builtin_amdgcn_raw_buffer_store_b128(tg_u32x4{pk[n].x, pk[n].y, pk[n].z, pk[n].w}, srs,
+        __builtin_amdgcn_raw_buffer_store_b128(tg_u32x4{pk[n].x ^ 0x80808080u, pk[n].y ^ 0x80808080u, pk[n].z ^ 0x80808080u,
+                                                        pk[n].w ^ 0x80808080u}, srs,
                                                static_cast<int>(g[n] * a.stride) + 16 * q, 0, 16);
     }
     kb += nb;
