@@ -112,7 +112,8 @@ int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* act
  * No wavefront ever waits for another one, so the launch itself cannot deadlock; a producer that waits for the WHOLE
  * batch before releasing the next step additionally needs every unit resident at once: at S = 4
  * tg_step_stream_layout chooses the games per wavefront so that this holds and refuses batches beyond what the
- * device keeps resident (about 4.5e5 games on the 256 CUs of an MI355X); S = 16 (one wavefront per game, the 4 KiB of
+ * device keeps resident (about 4.5e5 games on the 256 CUs of an MI355X; with ready == NULL tg_step_stream_i8 takes any B: units
+ * of 16 games run in rounds, progress -- if given -- has (B + 15) / 16 words); S = 16 (one wavefront per game, the 4 KiB of
  * a game in LDS) holds 32 games per CU = 8 192 on 256 CUs, beyond that the units run in rounds; S = 25 (one wavefront per game, the game's 15 625
  * bytes in registers) holds 16 games per CU = 4 096 on 256 CUs.  S = 4, S = 16 and S = 25 in this build
  * (TG_ERR_UNSUPPORTED otherwise), states 16-byte aligned, actions 4-byte aligned (S = 16: 16-byte).  This is a separate entry with its own metric: the single-step figures of tg_step_i8

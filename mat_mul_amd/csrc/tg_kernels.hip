@@ -2603,7 +2603,13 @@ int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8
   if (!state || !actions || !done) return fail(TG_ERR_INVALID, "%s: null pointer", fn);
   int64_t units = 0;
   int gpu_ = 0;
-  if (int rc = tg_step_stream_layout(B, S, &units, &gpu_)) return rc;
+  if (int rc = tg_step_stream_layout(B, S, &units, &gpu_)) {
+    // S = 4 beyond what the device keeps resident: without ready words no producer can be waiting for the whole batch, so
+    // the units (16 games each) simply run in rounds, every wavefront taking its games through all K steps
+    if (!(rc == TG_ERR_UNSUPPORTED && S == 4 && !ready && B > 0)) return rc;
+    units = (B + 15) / 16;
+    gpu_ = 16;
+  }
   // (a single game has no stride to speak of; S = 25 reads the 16-byte chunk that holds the game's last byte: it lies inside
   // the last game's final aligned 16 bytes, and only the game's own 9 bytes of it are ever written)
   if (!aligned16(state) || (game_stride_bytes % 16 != 0 && B > 1) || !(S == 16 ? aligned16(actions) : aligned4(actions)) ||

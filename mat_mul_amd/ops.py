@@ -229,8 +229,15 @@ def step_stream(state, actions, done=None, overflow=None, ready=None, progress=N
             # (device memory only: the stepper polls and publishes with agent-scope accesses; a host producer
             # releases a step by a fill / copy enqueued on another stream, not by writing mapped memory)
             raise TensorGameError("step_stream", -1, f"{name} must be a contiguous 32-bit vector on {dev}")
-    if progress is not None and progress.numel() < step_stream_layout(B, S, dev)[0]:
-        raise TensorGameError("step_stream", -1, "progress needs one word per unit (ops.step_stream_layout)")
+    if progress is not None:
+        try:
+            n_units = step_stream_layout(B, S, dev)[0]
+        except TensorGameError:
+            if ready is not None or S != 4:
+                raise
+            n_units = -(-B // 16)  # beyond the resident batch, without ready words: units of 16 games in rounds
+        if progress.numel() < n_units:
+            raise TensorGameError("step_stream", -1, "progress needs one word per unit (ops.step_stream_layout)")
     with torch.cuda.device(dev):
         call("tg_step_stream_i8", _ptr(state), _ptr(actions), _ptr(done), _ptr(overflow), _ptr(ready), _ptr(progress),
              _ptr(status), B, S, K, stride, int(shift), _stream(dev))

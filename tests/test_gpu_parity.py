@@ -1374,6 +1374,28 @@ def test_step_stream_waits_for_ready_words_and_times_out():
     assert int(status[0]) == 1 and np.array_equal(host(t2), two)
 
 
+def test_step_stream_beyond_the_resident_batch_runs_in_rounds_without_ready_words():
+    """S=4 with more games than the device keeps resident: refused with ready words (a producer waiting for the whole batch
+    would stall), accepted without -- units of 16 games run in rounds; BASELINE config 4 whole on one GPU."""
+    B, K = 1 << 20, 3
+    with pytest.raises(mat_mul_amd.TensorGameError, match="resident"):
+        ops.step_stream_layout(B, 4, DEV)
+    tok, tgt = ops.gen_demos(B, 4, K, DEV, seed=5)
+    st = ops.alloc_states(B, 4, DEV)
+    st.copy_(tgt)
+    acts = tok.permute(1, 0, 2).contiguous()
+    with pytest.raises(mat_mul_amd.TensorGameError, match="resident"):
+        ops.step_stream(st, acts, ready=torch.ones(K, dtype=torch.int32, device=DEV))
+    prog = torch.zeros(B // 16, dtype=torch.int32, device=DEV)
+    _, done = ops.step_stream(st, acts, progress=prog)
+    ref = ops.alloc_states(B, 4, DEV)
+    ref.copy_(tgt)
+    for k in range(K):
+        _, d = ops.step(ref, acts[k], out=ref)
+        assert torch.equal(done[k], d)
+    assert torch.equal(st, ref) and not bool(st.any()) and bool((prog == K).all())
+
+
 @pytest.mark.parametrize("S", [4, 16, 25])
 def test_env_step_stream_replays_demonstrations_to_zero(S):
     """TensorGameEnv.step_stream: R generated actions per game in one resident launch bring every target to zero, done[k]
