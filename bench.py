@@ -698,7 +698,8 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
                      "us_per_launch": round(sec * 1e6, 2), "GBps": round(nbytes / sec / 1e9, 1)})
     # the streamed stepper (its own entry and metric): K steps in ONE resident launch, the state stays in registers,
     # per step poll + 12 token bytes in + state and done written through + a progress word per wavefront
-    for (s2, b2, k2, r2) in [(4, 65536, 1008, 7), (4, 131072, 504, 7), (16, 8192, 512, 8), (25, 4096, 256, 8), (4, 1 << 20, 112, 7)]:
+    for (s2, b2, k2, r2) in [(4, 65536, 1008, 7), (4, 131072, 504, 7), (16, 8192, 512, 8), (25, 4096, 256, 8), (4, 1 << 20, 112, 7),
+                             (25, 32768, 64, 8)]:  # (the last two: BASELINE configs 4 and 5 whole on one GPU, units in rounds)
         tok, tgt = ops.gen_demos(b2, s2, r2, dev, seed=4)
         cyc = torch.cat([tok, tok], dim=1)
         cyc[:, r2:, :s2] = 2 - cyc[:, r2:, :s2]                  # the same terms with u negated: period 14
