@@ -728,14 +728,13 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
         sec = statistics.median(ts)
         ok = bool(torch.equal(st2, tgt)) and int(status[0]) == 0 and bool((prog == k2).all()) \
             and bool(dn[r2 - 1].all()) and not bool(dn[0].all())
-        # per step: tokens in, done out, and the state written through -- S=16: the 16-byte rows an action changes; S=4:
-        # the whole game once per block of steps
+        # per step: tokens in, done out, and the state written through: the whole game once per block of steps
         if s2 == 4:   # the state leaves once per block of D steps (D = 8 / 4 / 2 for 16 / 32 / more games per wavefront)
             moved = b2 * (3 * s2 + 1) + b2 * s2 ** 3 / {16: 8, 32: 4}.get(gpw, 2)
         elif s2 == 25:  # whole games once per block of 8 steps
             moved = b2 * (3 * s2 + 1) + b2 * s2 ** 3 / 8
-        else:
-            moved = b2 * (3 * s2 + 1) + 16.0 * changed_chunks_per_launch(s2, [acts[k] for k in range(2 * r2)])
+        else:           # S=16: whole games once per block of 8 steps
+            moved = b2 * (3 * s2 + 1) + b2 * s2 ** 3 / 8
         also.append({"workload": f"STREAMED tg_step_stream_i8: S={s2} batch={b2}, K={k2} steps in ONE launch, actions "
                                  f"consumed step by step ({'ready words pre-set' if ready is not None else 'no ready words: beyond the resident batch, units of 16 games in rounds'}), "
                                  f"progress published per wavefront; not the single-step metric",
@@ -743,9 +742,8 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
                      "GBps_moved": round(moved * k2 / sec / 1e9, 1),
                      "frac_of_hbm_peak_moved_bytes": round(moved * k2 / sec / 1e9 / HBM_PEAK_GBS, 4),
                      "launch_per_step_us": None,
-                     "note": "bytes moved per step: tokens in, done + state out (S=16: the changed 16-byte rows; S=4: the game "
-                             "once per block of released steps); the state is not re-read, it lives on chip (S=4, S=25: "
-                             "registers, S=16: LDS)"})
+                     "note": "bytes moved per step: tokens in, done out, the game once per block of released steps; the "
+                             "state is not re-read, it lives in registers"})
         del acts, dn
     # BASELINE config 5's generator (per-GPU share: 4 096 demos, S=25, R=64), with and without the change
     # of basis; bytes = target + tokens written (S^3 + 3SR per demo); replayed as a hipGraph

@@ -95,7 +95,7 @@ int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* act
  * done are DEVICE memory: the stepper polls and publishes with agent-scope (sc1) accesses, which do not order against
  * a host thread writing through mapped memory.  Same results as K calls of tg_step_i8(state, state, actions[k], done[k], ...);
  * what it removes is the dependent-launch boundary between two steps (1.55 us on MI355X, more than the step itself
- * at S=4, B=65 536): the stepper stays resident, keeps every game's state on chip (S = 4: registers, S = 16: LDS) and
+ * at S=4, B=65 536): the stepper stays resident, keeps every game's state on chip (in registers) and
  * per step only reads the token bytes and writes done[k] and -- at the latest when it publishes -- the new state through.
  * A wavefront takes all the steps it finds released at once (up to 8): with a producer that runs ahead the state and the
  * progress word advance in blocks of steps; a producer that releases step k+1 only after progress k+1 sees every step.
@@ -114,7 +114,7 @@ int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* act
  * tg_step_stream_layout chooses the games per wavefront so that this holds and refuses batches beyond what the
  * device keeps resident (about 4.5e5 games on the 256 CUs of an MI355X; with ready == NULL tg_step_stream_i8 takes any B: units
  * of 16 games run in rounds, progress -- if given -- has (B + 15) / 16 words); S = 16 (one wavefront per game, the 4 KiB of
- * a game in LDS) holds 32 games per CU = 8 192 on 256 CUs, beyond that the units run in rounds; S = 25 (one wavefront per game, the game's 15 625
+ * a game in registers) holds 32 games per CU = 8 192 on 256 CUs, beyond that the units run in rounds; S = 25 (one wavefront per game, the game's 15 625
  * bytes in registers) holds 16 games per CU = 4 096 on 256 CUs.  S = 4, S = 16 and S = 25 in this build
  * (TG_ERR_UNSUPPORTED otherwise), states 16-byte aligned, actions 4-byte aligned (S = 16: 16-byte).  This is a separate entry with its own metric: the single-step figures of tg_step_i8
  * never include it. */

@@ -1434,24 +1434,20 @@ __global__ __launch_bounds__(kBlock, 8) void s16_tracked_kernel(ApplyArgs a, int
 }
 
 // =============================================================================================
-// tg_step_stream_i8, S = 16: one wavefront per game, resident for all K steps.  A step reads 48 token bytes and writes
-// through only the rows the action changed (9 % with the reference's vocabulary) plus `done`: the launch-per-step kernel
-// re-reads 32 MiB per step at BASELINE config 3, this one moves ~3 MB.  8192 games = 32 wavefronts per CU on 256 CUs:
-// all resident (__launch_bounds__(256, 8), 17 KiB of LDS per workgroup).
-// Round 3: the game's 4 KiB live in LDS, not in 16 VGPRs per lane, and the stepper is the TRACKED step
-// (s16_tracked_kernel) against that image: the candidate rows' indices are compacted into the wavefront's 64-entry queue,
-// lane k takes entry k -- row from LDS, digit form (packed int16 form behind it), row back to LDS and written through --
-// and `done` comes from the carried count of non-zero entries (counted once at the start, then the changed rows' bytes
-// before and after), so no instruction touches the 91 % of the state a step leaves alone.  (The register-resident form
-// copied candidate rows into the queue and back and OR-ed all sixteen registers per step; at 64 VGPRs it had no room for
-// the pipelined token requests below.)  A game with more than 64 candidate rows (dense factors) takes four rounds, round n
-// the rows i = r + 4 n (at most 64 by construction).
+// tg_step_stream_i8, S = 16: one wavefront per game, resident for all K steps, the game in REGISTERS -- sixteen VGPRs of biased
+// state per lane (lane (r, j) holds rows (i = r + 4 n, j)); 8192 games = 32 wavefronts per CU on 256 CUs: all resident at
+// <= 64 VGPRs.  Every step updates all four rows of a lane in the digit form -- no queue, no LDS image, no divergent dense
+// pass; the L1 norm of a new row is this step's zero test and the next step's precondition (one bit per row); the game
+// is written through once per block.  Rows the digit form does not cover take the packed int16 form inline.
+// (Round 2 kept the state in registers too but compacted candidate rows through an LDS queue and OR-ed all sixteen
+// registers per step: 3.35 us per step at BASELINE config 3; round 3's first form -- the tracked step on an LDS image of the
+// game -- 2.27; this one 1.76: with the biased state a row costs four multiply-adds, four adds and four v_sad_u8, which is
+// less than finding out which rows to skip.)
 // =============================================================================================
 __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  constexpr int NW = kBlock / 64, QCAP = 64;
-  __shared__ __attribute__((aligned(16))) uint4 img[NW][256];  // row (i, j) = chunk 16 i + j
-  __shared__ int qm[NW][QCAP];                                 // (-u_i v_j) << 8 | chunk
+  constexpr int NW = kBlock / 64;
+  constexpr uint32_t BIAS = 0x80808080u;
   constexpr int D = 8;                                         // steps per block (below)
   __shared__ __attribute__((aligned(16))) uint32_t tokbuf[NW][D][12];  // the block's tokens: 48 bytes per step
   const int lane = threadIdx.x & 63;
@@ -1463,16 +1459,22 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
   const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.state, 0, static_cast<int>(a.B * a.stride), 0x00027000);
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(a.done, 0, 0x7fffffff, 0x00027000);
   const int soff = static_cast<int>(g * a.stride);
-  int nnz;  // uniform
+  // ---- the game -> registers, biased (x ^ 0x80808080): lane (r, j) holds rows (i = r + 4 n, j) = chunks lane + 64 n ----
+  auto l1_of = [&](const uint4& q) {
+    return static_cast<int>(__builtin_amdgcn_sad_u8(q.w, BIAS, __builtin_amdgcn_sad_u8(q.z, BIAS,
+                            __builtin_amdgcn_sad_u8(q.y, BIAS, __builtin_amdgcn_sad_u8(q.x, BIAS, 0u)))));
+  };
+  const int limit = s4_digits_limit(a.shift);
+  uint4 x[4];
+  uint32_t okbits = 0;  // bit n: row n's L1 norm <= limit (the digit form's precondition for the next step)
   {
     const int8_t* const src = a.state + g * a.stride + 16 * lane;
-    const uint4 p0 = *reinterpret_cast<const uint4*>(src), p1 = *reinterpret_cast<const uint4*>(src + 1024),
-                p2 = *reinterpret_cast<const uint4*>(src + 2048), p3 = *reinterpret_cast<const uint4*>(src + 3072);
-    img[wave][lane] = p0;
-    img[wave][lane + 64] = p1;
-    img[wave][lane + 128] = p2;
-    img[wave][lane + 192] = p3;
-    nnz = __builtin_amdgcn_readfirstlane(wave_sum(nz_bytes16(p0) + nz_bytes16(p1) + nz_bytes16(p2) + nz_bytes16(p3)));
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const uint4 q = *reinterpret_cast<const uint4*>(src + 1024 * n);
+      x[n] = uint4{q.x ^ BIAS, q.y ^ BIAS, q.z ^ BIAS, q.w ^ BIAS};
+      okbits |= (l1_of(x[n]) <= limit ? 1u : 0u) << n;
+    }
   }
   const uint32_t shp = (static_cast<uint32_t>(a.shift) & 0xFFFFu) | (static_cast<uint32_t>(a.shift) << 16);
   const bool wide_shift = static_cast<unsigned>(a.shift + 127) > 254u;  // uniform; factors may exceed 255
@@ -1526,10 +1528,11 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
       __builtin_amdgcn_s_sleep(2);
     }
   };
-  auto slot_of = [&](unsigned long long mm, int base) {
-    return base + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mm), 0u)));
-  };
-  // one step, its tokens in slot d of the block
+  // (the state is in its registers before the first asm load, or hipcc waits for it -- with vmcnt(0) -- inside the loop)
+#pragma unroll
+  for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(x[n].x), "+v"(x[n].y), "+v"(x[n].z), "+v"(x[n].w));
+  // one step, its tokens in slot d of the block: EVERY row of the lane in the digit form (no compaction: four rows of
+  // sixteen bytes, one product -u_i v_j each, the weight integers on the scalar unit)
   auto step = [&](int k, int d) {
     const uint4 u4 = *reinterpret_cast<const uint4*>(&tokbuf[wave][d][0]), w4 = *reinterpret_cast<const uint4*>(&tokbuf[wave][d][8]);
     const uint32_t vdw = tokbuf[wave][d][4 + ((lane & 15) >> 2)];
@@ -1544,78 +1547,54 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
     const int vj = __builtin_amdgcn_sbfe(static_cast<int>(vdw), 8 * (lane & 3), 8) - a.shift;
     auto wfetch = [&]() { return uint4{ws[0], ws[1], ws[2], ws[3]}; };  // (the 32-bit redo only)
     uint32_t ovf = 0;
-    // a row: digit form first (s16_chunk_digits; offered when all 48 tokens are <= 3: u and w on the scalar unit, the
-    // lanes' dwords of v by ballot), the packed int16 form with its weight pairs built off the common path for the rest
     const uint32_t uw_or = us[0] | us[1] | us[2] | us[3] | ws[0] | ws[1] | ws[2] | ws[3];
-    const bool small = (uw_or & 0xFCFCFCFCu) == 0 && __ballot((vdw & 0xFCFCFCFCu) != 0) == 0;
-    const int dig_limit = small ? s4_digits_limit(a.shift) : -1;  // uniform
+    const bool small = (uw_or & 0xFCFCFCFCu) == 0 && __ballot((vdw & 0xFCFCFCFCu) != 0) == 0;  // all 48 tokens <= 3 (uniform)
     const uint32_t Wd[4] = {ws[0] - shrep, ws[1] - shrep, ws[2] - shrep, ws[3] - shrep};
-    auto chunk = [&](const uint4& x, int uvn, uint32_t& cnz) {
-      uint4 res;
-      if (__builtin_expect(s16_chunk_digits(x, uvn, Wd, dig_limit, res, cnz), 1)) return res;
+    // X + uvn * Wd per dword: v_mad_u64_u32 from the inline constant 0 (full rate; no register pair to set up) and an add
+    auto fast_row = [&](const uint4& xb, int uvn) {
+      auto dig = [&](uint32_t xd, uint32_t w) {
+        uint64_t rr;
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(rr) : "v"(uvn), "s"(w) : "vcc");
+        return xd + static_cast<uint32_t>(rr);
+      };
+      return uint4{dig(xb.x, Wd[0]), dig(xb.y, Wd[1]), dig(xb.z, Wd[2]), dig(xb.w, Wd[3])};
+    };
+    // a row the digit form does not cover: un-bias, the packed int16 form (32-bit redo behind it), bias again
+    auto slow_row = [&](const uint4& xb, int uvn) {
       uint32_t w0 = ws[0], w1 = ws[1], w2 = ws[2], w3 = ws[3];
       asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));  // (or hipcc builds the weight pairs on the common path)
-      uint32_t wp[8];
+      uint32_t wp[8], cnz;
       unpack_pairs(uint4{w0, w1, w2, w3}, wp);
 #pragma unroll
       for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
-      return s16_chunk(x, uvn, wp, wfetch, a.shift, wide_shift, cnz, ovf);
+      const uint4 r4 = s16_chunk(uint4{xb.x ^ BIAS, xb.y ^ BIAS, xb.z ^ BIAS, xb.w ^ BIAS}, uvn, wp, wfetch, a.shift, wide_shift, cnz, ovf);
+      return uint4{r4.x ^ BIAS, r4.y ^ BIAS, r4.z ^ BIAS, r4.w ^ BIAS};
     };
-    // ---- candidate rows (u_i v_j != 0, i = r + 4 n) -> the queue; |u_i v_j| < 2^23 (int8 tokens, |shift| <= 127) ----
-    int uv[4], total = 0;  // total: uniform
-    unsigned long long m[4];
+    const bool all_fast = small && __ballot((okbits & 15u) != 15u) == 0;  // uniform
+    uint32_t l1tot = 0;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(us[n]), 8 * r, 8);  // -(u_i)
-      uv[n] = __mul24(ui, vj);  // (|factor| <= 255 here: full rate, v_mul_lo_u32 is a quarter-rate instruction)
-      m[n] = __ballot(uv[n] != 0);
-      total += __builtin_popcountll(m[n]);
+      const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(us[n]), 8 * r, 8);  // -(u_i), i = r + 4 n
+      const int uvn = __mul24(ui, vj);  // (|factor| <= 255 here: full rate, v_mul_lo_u32 is a quarter-rate instruction)
+      if (__builtin_expect(all_fast, 1)) x[n] = fast_row(x[n], uvn);
+      else if (small && ((okbits >> n) & 1u)) x[n] = fast_row(x[n], uvn);
+      else if (uvn != 0) x[n] = slow_row(x[n], uvn);
+      const int l1 = l1_of(x[n]);
+      l1tot += static_cast<uint32_t>(l1);
+      okbits = l1 <= limit ? okbits | (1u << n) : okbits & ~(1u << n);
     }
-    int delta = 0;
-    // the dense pass: lane e < cnt takes queue entry e -- row from LDS, arithmetic, row back and written through
-    auto pass = [&](int cnt) {
-      __builtin_amdgcn_wave_barrier();  // (LDS serves one wavefront's accesses in order)
-      if (lane < cnt) {
-        const int me = qm[wave][lane];
-        const int c = me & 255;
-        const uint4 x = img[wave][c];
-        uint32_t cnz;
-        const uint4 res = chunk(x, me >> 8, cnz);
-        if (res.x != x.x || res.y != x.y || res.z != x.z || res.w != x.w) {
-          // a changed row is written through at once (sc1: visible to other agents once this wavefront's vmcnt drains)
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{res.x, res.y, res.z, res.w}, srs, soff + 16 * c, 0, 16);
-          img[wave][c] = res;
-          delta += nz_bytes16(res) - nz_bytes16(x);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    };
-    if (__builtin_expect(total <= QCAP, 1)) {
-      int base = 0;  // uniform
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        if (uv[n] != 0) qm[wave][slot_of(m[n], base)] = static_cast<int>(static_cast<uint32_t>(uv[n]) << 8) | (lane + 64 * n);
-        base += __builtin_popcountll(m[n]);
-      }
-      pass(total);
-    } else {  // dense factors: four rounds, round n the rows i = r + 4 n (at most 64 by construction)
-#pragma unroll 1
-      for (int rd = 0; rd < 4; ++rd) {
-        int cnt = 0;  // uniform
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          if (n != rd) continue;
-          if (uv[n] != 0) qm[wave][slot_of(m[n], 0)] = static_cast<int>(static_cast<uint32_t>(uv[n]) << 8) | (lane + 64 * n);
-          cnt = __builtin_popcountll(m[n]);
-        }
-        pass(cnt);
-      }
-    }
-    nnz += __builtin_amdgcn_readfirstlane(wave_sum(delta));
+    const bool any_nz = __ballot(l1tot != 0) != 0;
     if (lane == 0)
-      __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(nnz == 0 ? 1 : 0), drs,
+      __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(any_nz ? 0 : 1), drs,
                                            static_cast<int>(static_cast<int64_t>(k) * a.B + g), 0, 16);
     if (__builtin_expect(ovf != 0, 0) && a.overflow) a.overflow[g] = 1;
+  };
+  // the game leaves once per block (write-through, sc1), as in s4_stream_kernel
+  auto put_state = [&]() {
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{x[n].x ^ BIAS, x[n].y ^ BIAS, x[n].z ^ BIAS, x[n].w ^ BIAS}, srs,
+                                             soff + 16 * (lane + 64 * n), 0, 16);
   };
   int kb = 0;                                                  // first step of the block (uniform)
   int nb = a.ready ? wait_released(0) : (a.K < D ? a.K : D);   // its steps: released, not yet requested
@@ -1635,6 +1614,7 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
     arrived();
 #pragma unroll 1
     for (int d = 0; d < nb; ++d) step(kb + d, d);
+    put_state();
     kb += nb;
     fresh = false;
     if (kb >= a.K) break;

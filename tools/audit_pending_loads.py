@@ -43,7 +43,7 @@ def kernel_body(src, name):
 
 def audit(src):
     problems = []
-    names = [l.split(":")[0] for l in src if re.match(r"^_ZN2tg1[67]s(4|16)_stream_kernel\w*:", l)]
+    names = [l.split(":")[0] for l in src if re.match(r"^_ZN2tg\d+s(4|16)_stream_kernel\w*:", l)]
     if len(names) < 5:
         problems.append(f"expected five s4/s16 stream kernels, found {len(names)}")
     for nm in names:
