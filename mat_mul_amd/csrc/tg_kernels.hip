@@ -1264,6 +1264,33 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
     return LINES ? ((cm >> (lane & ~7)) & 0xFFull) != 0 : changed;
   };
 
+  if constexpr (!LINES) {
+    // Cache-resident batches (round 3, late): EVERY row by its own lane, no queue.  The queue was built when a row cost ~32
+    // instructions (packed int16 form) and nine in ten rows are untouched; in the digit form a row costs ~20 and the
+    // compaction -- ballots, slots, two LDS trips, a divergent dense pass -- costs more than it saves: 5.61 -> 5.51 us at
+    // BASELINE config 3, 3.08 -> 2.87 at 2 048 games.  (The whole-line variants below still hand rows through the queue:
+    // their owners store whole 128-byte lines.)
+    auto one = [&](int n, const uint4& pn, uint32_t udw) {
+      const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(udw), 8 * r, 8);  // -(u_i), i = r + 4 n
+      const int uvn = ui * vj;
+      uint32_t cnz;
+      const uint4 res = chunk(pn, uvn, cnz);
+      nz |= cnz;
+      // in place, a row the action left as it was needs no store
+      if (live && (!inplace || differs(res, pn))) *reinterpret_cast<uint4*>(out + 16 * (lane + 64 * n)) = res;
+    };
+    one(0, p0, uq.x);
+    one(1, p1, uq.y);
+    one(2, p2, uq.z);
+    one(3, p3, uq.w);
+    const bool any_nz0 = __ballot(nz != 0) != 0;
+    const bool any_ovf0 = __ballot(ovf != 0) != 0;
+    if (lane == 0 && live) {
+      a.done[g] = any_nz0 ? 0 : 1;
+      if (a.overflow && any_ovf0) a.overflow[g] = 1;
+    }
+    return;
+  }
   // ---- which of the lane's rows does the action touch?  candidates -> the wavefront's queue ----
   int total = 0;  // uniform
   auto enqueue = [&](int n, const uint4& pn, uint32_t udw, int& uvn, int& slot) {
