@@ -1298,7 +1298,8 @@ def test_step_is_the_same_in_both_sweep_directions(S, B):
 # ------------------------------------------------------------------ tg_step_stream_i8 (K steps, one launch, actions arriving step by step)
 @pytest.mark.parametrize("S,B,K", [(4, 1, 3), (4, 16, 5), (4, 70, 9), (4, 1000, 14), (4, 4099, 6),
                                    (16, 1, 4), (16, 7, 9), (16, 130, 6), (16, 1030, 5),
-                                   (25, 1, 4), (25, 6, 11), (25, 37, 9), (25, 210, 5)])
+                                   (25, 1, 4), (25, 6, 11), (25, 37, 9), (25, 210, 5),
+                                   (16, 8300, 3), (25, 4200, 3)])     # (the last two: more games than stay resident -- rounds)
 def test_step_stream_equals_k_single_steps(S, B, K):
     """Every step of the streamed stepper equals tg_step_i8 / the oracle: state, done[k], sticky overflow; ragged
     batches, terminal games, an overflowing game, progress words; padded and packed layouts."""
