@@ -359,6 +359,13 @@ __device__ __forceinline__ uint32_t s4_digits_pre(const uint4& in_slice, uint32_
   return l1;
 }
 // wave-uniform: the largest slice norm the digit form accepts under this shift, -1 when it never applies
+// a * b mod 2^32 by v_mad_u64_u32 (full rate on gfx950: 4.9 issue cycles; hipcc's v_mul_lo_u32 is a quarter-rate instruction)
+__device__ __forceinline__ uint32_t mul_lo_mad(uint32_t x, uint32_t y) {
+  uint64_t r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(x), "v"(y) : "vcc");
+  return static_cast<uint32_t>(r);
+}
+
 __host__ __device__ __forceinline__ int s4_digits_limit(int shift) {
   const int F = shift > 3 - shift ? shift : 3 - shift;
   return static_cast<unsigned>(shift) <= 3u ? 127 - F * F * F : -1;
@@ -370,7 +377,7 @@ __device__ __forceinline__ bool s4_step_digits(const uint32_t (&xb)[4], uint32_t
   // -(u_i): byte q of du comes down by v_alignbyte_b32 (shifts by q BYTES: no 8 * q), then one SDWA subtract
   const uint32_t nui = static_cast<uint32_t>(shift) - (__builtin_amdgcn_alignbyte(du, du, static_cast<uint32_t>(q)) & 255u);
   const uint32_t W = dw - static_cast<uint32_t>(shift) * 0x01010101u;
-  const uint32_t G = nui * W;
+  const uint32_t G = mul_lo_mad(nui, W);
   uint32_t o[4], vj[4];
   asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(vj[0]) : "v"(dv), "s"(shift));
   asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(vj[1]) : "v"(dv), "s"(shift));
@@ -408,7 +415,7 @@ __device__ __forceinline__ void s4_step_biased(uint4& xb, uint32_t& l1, uint32_t
   const uint32_t wide = (du | dv | dw) & 0xFCFCFCFCu;
   const uint32_t nui = static_cast<uint32_t>(shift) - (__builtin_amdgcn_alignbyte(du, du, static_cast<uint32_t>(q)) & 255u);
   const uint32_t W = dw - static_cast<uint32_t>(shift) * 0x01010101u;
-  const uint32_t G = nui * W;
+  const uint32_t G = mul_lo_mad(nui, W);
   uint32_t vj[4];
   asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(vj[0]) : "v"(dv), "s"(shift));
   asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(vj[1]) : "v"(dv), "s"(shift));
