@@ -69,15 +69,13 @@ __device__ __forceinline__ int mad24_sgpr(int a_uniform, int b, int c) {
   return r;
 }
 
-// number of non-zero bytes of a dword: fold each byte onto its low bit, then popcount
-__device__ __forceinline__ int count_nonzero_bytes(uint32_t x) {
-  // bit 7 of a byte <- "byte != 0": adding 0x7f to the low seven bits carries into bit 7 iff they are non-zero, OR x
-  // brings in bit 7 itself (no carry leaves a byte: 0x7f + 0x7f < 0x100); five instructions, the popcount accumulates
-  const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
-  return __popc(t & 0x80808080u);
+// number of non-zero bytes of a dword, accumulated: TWO instructions.  v_msad_u8 sums |a_i - b_i| over the bytes with
+// b_i != 0, and x ^ 0x01010101 differs from x by exactly one in every byte (round 3; the mask-and-popcount form took four)
+__device__ __forceinline__ int count_nonzero_bytes(uint32_t x, int acc = 0) {
+  return static_cast<int>(__builtin_amdgcn_msad_u8(x ^ 0x01010101u, x, static_cast<uint32_t>(acc)));
 }
 __device__ __forceinline__ int count_nonzero_bytes(const uint4& q) {
-  return count_nonzero_bytes(q.x) + count_nonzero_bytes(q.y) + count_nonzero_bytes(q.z) + count_nonzero_bytes(q.w);
+  return count_nonzero_bytes(q.x, count_nonzero_bytes(q.y, count_nonzero_bytes(q.z, count_nonzero_bytes(q.w))));
 }
 
 // ---- the 64-bit state key (tg_hash_u64, include/tensor_game.h) -------------------------------

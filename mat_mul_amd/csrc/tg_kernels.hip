@@ -1974,7 +1974,9 @@ __global__ __launch_bounds__(kBlock) void done_kernel(const int8_t* state, uint8
       for (; e < body; e += step) cnt += count_nonzero_bytes(*reinterpret_cast<const uint4*>(p + e));
     }
     for (int e = body + lt; e < N; e += lpg) cnt += p[e] != 0;
-    for (int off = lpg >> 1; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lpg == 64) cnt = wave_sum(cnt);  // (DPP: no LDS round trips; uniform)
+    else
+      for (int off = lpg >> 1; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
     if (lt == 0 && live) {
       done[g] = cnt == 0;
       if (nnz) nnz[g] = cnt;
