@@ -1129,15 +1129,11 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
 // (The staged packed_kernel needs three barriers.)  Factors beyond the 16-bit path's range are handled
 // by the same wavefront in 32-bit.  Requires 16-byte aligned state and actions.
 //
-// Arithmetic only where the action acts.  A row (i, j) changes only when u_i v_j != 0 -- 9 % of the rows under the
-// reference's factor distribution -- but a wave instruction covers four values of i and all sixteen j, so skipping
-// per instruction almost never fires, and the unpack / multiply-add / pack / range test of all four chunks was 45 % of
-// the kernel (measured by ablation: 4.0 us without it at BASELINE config 3, 6.6 with; 83 us against 148 at 131 072
-// games, where 83 us is also what a bare read of the same bytes takes).  So the rows that change are COMPACTED:
-// each lane appends its candidate chunks (16 bytes + chunk index + the product -u_i v_j) to a 64-entry queue of its
-// wavefront in LDS (slot = running count + mbcnt of the ballot), and one dense pass -- lane k takes entry k --
-// does the arithmetic and stores the result straight to the game.  Unchanged chunks only feed the zero test.
-// A game with more than 64 candidate rows (dense factors) takes the direct form: all four chunks of every lane.
+// History: in rounds 2 and 3 the rows the action touches (u_i v_j != 0: 9 % under the reference's factor distribution) were
+// COMPACTED into a 64-entry queue of the wavefront in LDS and worked on in one dense pass, because the unpack / multiply-add
+// / pack / range test of all four chunks in the packed int16 form was 45 % of the kernel (4.0 us without it at BASELINE
+// config 3, 6.6 with).  With the digit form a row costs ~20 instructions and the kernel does every row in its own lane
+// again (comment inside); the queue is gone.
 // =============================================================================================
 // one chunk: x - (-uv) ... i.e. x + uvn * w, uvn = -u_i v_j; saturating int16 form, 32-bit redo when the range test fails
 // (wfetch: the game's 16 w tokens again, for the redo only -- keeping them would cost four registers on the common path)
@@ -1205,8 +1201,7 @@ __device__ __forceinline__ uint4 s16_chunk(const uint4& x, int uvn, const uint32
 // LINES: stores at 128-byte-line granularity -- a chunk is stored when any of the eight chunks of its line changed.
 // For batches that stream from HBM: a partially written line costs the memory side a read-modify-write (measured at
 // 131 072 games: 148 us with 16-byte or 64-byte stores, 130 us with whole lines, although those write 1.7x the bytes).
-// The dense pass then hands its results back through the queue and the owners store.  Cache-resident batches keep the
-// 16-byte stores straight from the dense pass (no second trip through LDS: 5.8 us against 6.2 at BASELINE config 3).
+// Cache-resident batches store only the rows that changed.
 // NTL: the state is read by non-temporal loads.  With whole-line stores and a batch beyond the 256 MiB Infinity Cache
 // that is worth a quarter of the launch (131 072 games = 512 MiB: 131.5 -> 99.0 us; 262 144 games: 260 -> 232); up to
 // ~300 MiB it is neutral to harmful (77 000 games = 301 MiB: 58.7 / 60.3 us, 65 536 games: 50.3 / 52.0, BASELINE config
@@ -1216,9 +1211,6 @@ __device__ __forceinline__ uint4 s16_chunk(const uint4& x, int uvn, const uint32
 template <int MODE, bool LINES, bool NTL = false, bool DIG = true>
 __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyArgs a) {  // (LINES keeps the inputs to the end)
   static_assert(MODE == STEP, "s16_step_kernel: single step only");
-  constexpr int QCAP = 64;  // queue entries per wavefront
-  __shared__ __attribute__((aligned(16))) uint4 qd[kBlock / 64][QCAP];  // the candidate chunks
-  __shared__ __attribute__((aligned(8))) int2 qm[kBlock / 64][QCAP];    // (chunk index, -u_i v_j)
   // (the wavefront index is uniform; saying so lets the game's tokens come by scalar loads)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   int64_t g = static_cast<int64_t>(sweep_index(blockIdx.x, gridDim.x, a.sweep)) * (kBlock / 64) + wave;
@@ -1271,20 +1263,22 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
     return LINES ? ((cm >> (lane & ~7)) & 0xFFull) != 0 : changed;
   };
 
-  if constexpr (!LINES) {
-    // Cache-resident batches (round 3, late): EVERY row by its own lane, no queue.  The queue was built when a row cost ~32
-    // instructions (packed int16 form) and nine in ten rows are untouched; in the digit form a row costs ~20 and the
-    // compaction -- ballots, slots, two LDS trips, a divergent dense pass -- costs more than it saves: 5.61 -> 5.51 us at
-    // BASELINE config 3, 3.08 -> 2.87 at 2 048 games.  (The whole-line variants below still hand rows through the queue:
-    // their owners store whole 128-byte lines.)
+  {
+    // EVERY row by its own lane (round 3, late).  Rounds 2-3 compacted the rows the action touches (9 %) into a queue of
+    // the wavefront in LDS and did the arithmetic in one dense pass: that paid while a row cost ~32 instructions (packed
+    // int16 form).  In the digit form a row costs ~20, and the compaction -- ballots, slots, two LDS trips, a divergent
+    // dense pass, for the whole-line variants a third trip back to the owners -- costs more than it saves: 5.61 -> 5.51 us
+    // at BASELINE config 3, 3.08 -> 2.87 at 2 048 games, equal within 1.5 % from 128 MiB to 2 GiB of states.
     auto one = [&](int n, const uint4& pn, uint32_t udw) {
       const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(udw), 8 * r, 8);  // -(u_i), i = r + 4 n
       const int uvn = ui * vj;
       uint32_t cnz;
       const uint4 res = chunk(pn, uvn, cnz);
       nz |= cnz;
-      // in place, a row the action left as it was needs no store
-      if (live && (!inplace || differs(res, pn))) *reinterpret_cast<uint4*>(out + 16 * (lane + 64 * n)) = res;
+      // in place, a row the action left as it was needs no store (LINES: unless one of the eight rows of its line changed)
+      const bool chg = differs(res, pn);
+      const bool st = LINES ? stores(chg, __ballot(chg)) : (!inplace || chg);
+      if (live && st) *reinterpret_cast<uint4*>(out + 16 * (lane + 64 * n)) = res;
     };
     one(0, p0, uq.x);
     one(1, p1, uq.y);
@@ -1296,85 +1290,6 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
       a.done[g] = any_nz0 ? 0 : 1;
       if (a.overflow && any_ovf0) a.overflow[g] = 1;
     }
-    return;
-  }
-  // ---- which of the lane's rows does the action touch?  candidates -> the wavefront's queue ----
-  int total = 0;  // uniform
-  auto enqueue = [&](int n, const uint4& pn, uint32_t udw, int& uvn, int& slot) {
-    const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(udw), 8 * r, 8);  // -(u_i), i = r + 4 n
-    uvn = ui * vj;
-    const bool cand = uvn != 0;
-    const unsigned long long m = __ballot(cand);
-    slot = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
-                                                               __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
-    if (cand) {
-      if (slot < QCAP) {
-        qd[wave][slot] = pn;
-        qm[wave][slot] = int2{lane + 64 * n, uvn};
-      }
-    } else {
-      nz |= pn.x | pn.y | pn.z | pn.w;
-      if (!LINES && !inplace && live) *reinterpret_cast<uint4*>(out + 16 * (lane + 64 * n)) = pn;
-    }
-    total += __builtin_popcountll(m);
-  };
-  int uv0, uv1, uv2, uv3, s0, s1, s2, s3;
-  enqueue(0, p0, uq.x, uv0, s0);
-  enqueue(1, p1, uq.y, uv1, s1);
-  enqueue(2, p2, uq.z, uv2, s2);
-  enqueue(3, p3, uq.w, uv3, s3);
-  if (total <= QCAP) {
-    // ---- dense pass: lane k takes entry k (LDS serves one wavefront's accesses in order: no barrier) ----
-    __builtin_amdgcn_wave_barrier();
-    if (lane < total) {
-      const uint4 x = qd[wave][lane];
-      const int2 me = qm[wave][lane];
-      uint32_t cnz;
-      const uint4 res = chunk(x, me.y, cnz);
-      nz |= cnz;
-      if constexpr (LINES) {
-        qd[wave][lane] = res;  // back to the owner, who stores whole lines
-      } else {
-        // in place, a row the action left as it was (w zero there, or wrapped back) needs no store
-        if (live && (!inplace || differs(res, x))) *reinterpret_cast<uint4*>(out + 16 * me.x) = res;
-      }
-    }
-    if constexpr (LINES) {
-      __builtin_amdgcn_wave_barrier();
-      auto finish = [&](int n, const uint4& pn, int uvn, int slot) {
-        uint4 res = pn;
-        if (uvn != 0) res = qd[wave][slot];
-        const bool chg = differs(res, pn);
-        if (live && stores(chg, __ballot(chg))) *reinterpret_cast<uint4*>(out + 16 * (lane + 64 * n)) = res;
-      };
-      finish(0, p0, uv0, s0);
-      finish(1, p1, uv1, s1);
-      finish(2, p2, uv2, s2);
-      finish(3, p3, uv3, s3);
-    }
-  } else {
-    // ---- dense factors: every candidate chunk by its own lane ----
-    auto direct = [&](int n, const uint4& pn, int uvn) {
-      uint4 res = pn;
-      if (uvn != 0) {
-        uint32_t cnz;
-        res = chunk(pn, uvn, cnz);
-        nz |= cnz;
-      }
-      const bool chg = differs(res, pn);
-      const bool st = LINES ? stores(chg, __ballot(chg)) : (uvn != 0 && (chg || !inplace));
-      if (live && st) *reinterpret_cast<uint4*>(out + 16 * (lane + 64 * n)) = res;
-    };
-    direct(0, p0, uv0);
-    direct(1, p1, uv1);
-    direct(2, p2, uv2);
-    direct(3, p3, uv3);
-  }
-  const bool any_nz = __ballot(nz != 0) != 0;
-  const bool any_ovf = __ballot(ovf != 0) != 0;
-  if (lane == 0 && live) {
-    a.done[g] = any_nz ? 0 : 1;
-    if (a.overflow && any_ovf) a.overflow[g] = 1;
   }
 }
 
@@ -1702,10 +1617,8 @@ __global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(a.done, 0, 0x7fffffff, 0x00027000);
   const int soff = static_cast<int>(g * a.stride);
   const bool act = lane < TL;
-  const int ws = (16 * lane) % 25, r0l = (16 * lane) / 25, k0 = 25 - ws;  // window start, first row, bytes in that row
   const uint32_t shrep = static_cast<uint32_t>(a.shift) * 0x01010101u;
   const int limit = s4_digits_limit(a.shift);
-  const uint32_t actm = act ? ~0u : 0u;
   auto l1_of = [&](const uint4& q) {
     return static_cast<int>(__builtin_amdgcn_sad_u8(q.w, BIAS, __builtin_amdgcn_sad_u8(q.z, BIAS,
                             __builtin_amdgcn_sad_u8(q.y, BIAS, __builtin_amdgcn_sad_u8(q.x, BIAS, 0u)))));
@@ -2358,7 +2271,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       const bool nt_band = B * a.in_stride >= kNtLoadsFromBytes && B * a.in_stride < kNtLoadsToBytes;
       // (as at S = 25: beyond 1.25 GiB five workgroups per CU instead of eight -- 2 GiB of states, dynamic LDS 0 / 8 / 14 / 20 /
       // 26 / 34 KB: 516 / 516 / 515 / 514 / 504 / 506 us)
-      int s16_lds_pad = B * a.in_stride >= kNtLoadsToBytes ? 26000 : 0;
+      int s16_lds_pad = B * a.in_stride >= kNtLoadsToBytes ? 32000 : 0;  // (the kernel has no LDS of its own: 160 KB / 32 000 = 5)
 #ifdef TG_AB_SWITCHES
       if (getenv("TG_S16_LDS_PAD")) s16_lds_pad = atoi(getenv("TG_S16_LDS_PAD"));
       if (TG_SWITCH("TG_S16_NO_DIGITS")) {  // the packed int16 form alone
