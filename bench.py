@@ -405,7 +405,7 @@ def roofline(B, S, K, event_ms_samples, needed_bytes=None, copy=None, footprint=
 
 
 # ------------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(B, S, budget_s=12.0):
+def cpu_baseline(B, S, budget_s=12.0, sweep_s=1.0):
     """The reference-dtype torch-CPU port on this host: fp32 (B,1,S,S,S) state, int64 tokens.
     torch's intra-op pool is tried at a few sizes (a 256-thread pool thrashes on these small
     elementwise ops); the fastest is timed for the budget and its size reported as `cores`."""
@@ -421,7 +421,7 @@ def cpu_baseline(B, S, budget_s=12.0):
         torch.set_num_threads(nt)
         P.env_step(state0, acts)  # warm-up
         n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 1.0 or n < 2:
+        while time.perf_counter() - t0 < sweep_s or n < 2:
             P.env_step(state0, acts)
             n += 1
         trials[nt] = n / (time.perf_counter() - t0)
@@ -463,9 +463,10 @@ def cpu_baseline(B, S, budget_s=12.0):
         c_rate = f"unavailable: {e}"
     return {"value": round(B * n / el, 1), "unit": "steps/s", "cores": best, "kind": "port",
             "c_int8_port_1thread_steps_per_s": c_rate,
-            "sample": f"{n} batched steps of the same workload (B={B}, S={S}; fp32 state, int64 tokens, "
-                      f"torch-CPU op sequence of get_child_states + zero check) in {el:.1f} s; "
-                      f"thread-count sweep (batched steps/s): " + ", ".join(f"{k}:{v:.1f}" for k, v in trials.items()),
+            "sample": f"{n} batched steps of the same workload (B={B}, S={S}) in {el:.1f} s",
+            "sample_detail": "fp32 (B,1,S,S,S) state, int64 tokens, the torch-CPU op sequence of get_child_states + zero "
+                             "check (oracle/ref_dtype_torch.py); thread-count sweep (batched steps/s): "
+                             + ", ".join(f"{k}:{v:.1f}" for k, v in trials.items()),
             "host_cpus_available": avail, "per_game_loop_steps_per_s": round(single, 1)}
 
 
@@ -485,6 +486,196 @@ def self_launch(n_gpus: int, argv) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+# ------------------------------------------------------------------------------------------- the contract line
+MAX_LINE_BYTES = 4096   # the driver keeps a tail of stdout; round 3's 28.7 KB line was cut and never parsed
+TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "samples", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "dry_run")
+CONFIG_KEYS = ("workload", "S", "batch_per_gpu", "global_batch", "launch", "parallelism", "batch_rank0", "last_game_id")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "frac_traffic", "traffic", "kernel",
+                 "bytes_per_launch", "needed_bytes_per_launch", "avg_launch_us", "copy_ceiling_GBps", "hbm_copy_ceiling_GBps")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "host_cpus_available", "per_game_loop_steps_per_s")
+# numeric side objects of the line: S=16 (BASELINE config 3), the sharded extras of an N>1 run, config 4 on one GPU
+EXTRA_KEYS = ("value_s16", "ms_per_step_s16", "roofline_s16", "s16_strong", "s4_weak", "s4_strong", "streamed_s4", "cfg4_one_gpu",
+              "generator_cfg5", "also_file", "also_ok", "shards")
+
+
+def lean(obj, keys):
+    return {k: obj[k] for k in keys if k in obj}
+
+
+def contract_line(full) -> str:
+    """The ONE line the driver parses, printed LAST: the contract fields, numeric roofline / cpu_baseline objects and
+    the S=16 / sharded figures -- no prose, no sample lists.  Everything else (`also`, methods, notes, per-sample
+    timings) goes to bench_also.json.  Raises if the line would not fit the driver's stdout tail."""
+    out = lean(full, TOP_KEYS)
+    out["config"] = lean(full.get("config", {}), CONFIG_KEYS)
+    if "roofline" in full:
+        out["roofline"] = lean(full["roofline"], ROOFLINE_KEYS)
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = lean(full["cpu_baseline"], CPU_KEYS)
+    for k in EXTRA_KEYS:
+        if k in full:
+            v = full[k]
+            out[k] = lean(v, ROOFLINE_KEYS) if k.startswith("roofline") else v
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= MAX_LINE_BYTES or "\n" in line:
+        raise RuntimeError(f"bench contract line is {len(line)} bytes (limit {MAX_LINE_BYTES}): move fields to bench_also.json")
+    return line
+
+
+def write_side_file(full, also):
+    """bench_also.json next to bench.py (and under gpurun_out/ when that exists, so a gpurun call brings it back):
+    the full headline object with its prose and sample lists, and the `also` workloads."""
+    doc = {"headline": full, "also": also}
+    paths = [ROOT / "bench_also.json"]
+    if (ROOT / "gpurun_out").is_dir():
+        paths.append(ROOT / "gpurun_out" / "bench_also.json")
+    written = None
+    for p in paths:
+        try:
+            p.write_text(json.dumps(doc, indent=1) + "\n")
+            written = written or p.name
+        except OSError:
+            pass
+    return written
+
+
+def demo_rank(S):
+    return 7 if S == 4 else 8
+
+
+def sharded_step(group, G, S, dev, mode, K, W, samples, seed=0):
+    """One sharded measurement, every rank taking part: G games in total, this rank's contiguous range of global ids,
+    W warm-up + `samples` samples of exactly K in-place steps, each bracketed by barrier + synchronize; the wall time
+    per sample and the event-timed launch time are MAX-reduced over the ranks."""
+    from mat_mul_amd import shard_range
+
+    lo, hi = shard_range(G, group.rank, group.world)
+    B = hi - lo
+    start, sched, _ = make_demo_schedule(B, S, demo_rank(S), dev, seed, lo)
+    tm = StepTimer(start, sched, dev, mode)
+    res = tm.measure(K, W, samples, sync=group.barrier)
+    my_launch_us = statistics.median(res["event_ms"]) * 1e3 / K
+    my_fixed_us = statistics.median(res["run_ms_lead_in_only"]) * 1e3 - res["lead_in"] * my_launch_us
+    reduced = group.max_over_ranks(*res["wall_s"], 0.0 if res["ok"] else 1.0, my_launch_us, my_fixed_us)
+    walls, bad, launch_us_max, fixed_us_max = list(reduced[:-3]), reduced[-3], reduced[-2], reduced[-1]
+    if bad:
+        raise SystemExit(f"bench self-check failed (S={S}, {G} games over {group.world} ranks): the state did not return "
+                         "to its start after full cycles")
+    del tm
+    return {"B": B, "G": G, "S": S, "K": K, "walls": walls, "wall": statistics.median(walls), "launch_us_max": launch_us_max,
+            "fixed_us_max": fixed_us_max, "res": res, "sched": sched}
+
+
+def shard_figures(m):
+    """The numeric summary of one sharded_step for the line: whole-job steps/s on the wall clock and on kernel time."""
+    return {"global_batch": m["G"], "batch_per_gpu": m["G"] // max(1, m.get("world", 1)),
+            "value": round(m["G"] * m["K"] / m["wall"], 1), "ms_per_step": round(m["wall"] * 1e3 / m["K"], 6),
+            "launch_us": round(m["launch_us_max"], 3), "event_steps_per_s": round(m["G"] / (m["launch_us_max"] * 1e-6), 1)}
+
+
+def streamed_time(b2, s2, k2, dev, seed=4, gid0=0, reps=5):
+    """tg_step_stream_i8 on b2 games: K steps in ONE resident launch, the actions consumed step by step.  Returns
+    (seconds per launch, ok, games per wavefront, 'ready' | 'rounds')."""
+    from mat_mul_amd import ops
+
+    r2 = demo_rank(s2)
+    tok, tgt = ops.gen_demos(b2, s2, r2, dev, seed=seed, game_id_offset=gid0)
+    cyc = torch.cat([tok, tok], dim=1)
+    cyc[:, r2:, :s2] = 2 - cyc[:, r2:, :s2]                  # the same terms with u negated: period 2 r2
+    acts = cyc.permute(1, 0, 2).contiguous().repeat(k2 // (2 * r2), 1, 1)   # (K, B, 3S) step-major
+    st2 = ops.alloc_states(b2, s2, dev)
+    st2.copy_(tgt)
+    dn = torch.empty((k2, b2), dtype=torch.uint8, device=dev)
+    if b2 <= ops.step_stream_capacity(s2, dev):
+        n_units, gpw = ops.step_stream_layout(b2, s2, dev)
+        ready = torch.ones(k2, dtype=torch.int32, device=dev)    # pre-set: the producer is never the bottleneck
+    else:  # beyond the resident batch: no ready words, the units (S=4: 16 games each, S=16/25: one game) run in rounds
+        n_units, gpw, ready = (-(-b2 // 16), 16, None) if s2 == 4 else (b2, 1, None)
+    prog = torch.zeros(n_units, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    fn = lambda: ops.step_stream(st2, acts, done=dn, ready=ready, progress=prog, status=status)
+    fn()
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    ok = bool(torch.equal(st2, tgt)) and int(status[0]) == 0 and bool((prog == k2).all()) \
+        and bool(dn[r2 - 1].all()) and not bool(dn[0].all())
+    return statistics.median(ts), ok, gpw, ("ready" if ready is not None else "rounds")
+
+
+def sharded_extras(group, world, dev, mode, K, headline):
+    """N > 1 only, after the headline's timed region, every rank taking part: BASELINE config 3 sharded weak (8 192 games
+    per GPU) and strong (8 192 in total), config 4 strong (2^20 games in total) with its single-GPU denominator and the
+    resident stepper on the same share, measured in the same run."""
+    from mat_mul_amd import shard_range
+
+    rank = group.rank
+    Kx = max(14, min(K, 512))
+    out = {}
+    m = sharded_step(group, 8192 * world, 16, dev, mode, Kx, 16, 5, seed=1)
+    m["world"] = world
+    if rank == 0:
+        f = shard_figures(m)
+        out["value_s16"], out["ms_per_step_s16"] = f["value"], f["ms_per_step"]
+        out["roofline_s16"] = roofline(m["B"], 16, Kx, m["res"]["event_ms"], needed_bytes_per_launch(m["B"], 16, m["sched"]))
+    m = sharded_step(group, 8192, 16, dev, mode, Kx, 16, 5, seed=1)
+    m["world"] = world
+    if rank == 0:
+        out["s16_strong"] = shard_figures(m)
+    G4 = 1 << 20
+    if headline["S"] == 4 and headline["G"] == G4:     # --scaling strong: config 4 IS the headline; add the weak figure
+        m = dict(headline, world=world)
+        Kx4 = headline["K"]
+        mw = sharded_step(group, 65536 * world, 4, dev, mode, Kx, 16, 5, seed=0)
+        mw["world"] = world
+        if rank == 0:
+            out["s4_weak"] = shard_figures(mw)
+    else:
+        m = sharded_step(group, G4, 4, dev, mode, Kx, 16, 5, seed=0)
+        m["world"] = world
+        Kx4 = Kx
+    # the resident stepper on this rank's share of config 4 (K steps in one launch); MAX over ranks
+    lo, hi = shard_range(G4, rank, world)
+    ks = 14 * max(1, min(Kx, 504) // 14)
+    group.barrier()
+    sec, ok, gpw, how = streamed_time(hi - lo, 4, ks, dev, gid0=lo)
+    (sec_max, bad) = group.max_over_ranks(sec, 0.0 if ok else 1.0)
+    if bad:
+        raise SystemExit("bench self-check failed: streamed stepper on the config-4 share")
+    if rank == 0:
+        f = shard_figures(m)
+        # the same GLOBAL batch on ONE GPU (rank 0 alone): the denominator of the strong-scaling speed-up, same run
+        s1, sc1, _ = make_demo_schedule(G4, 4, 7, dev, 0, 0)
+        t1 = StepTimer(s1, sc1, dev, mode)
+        k1 = max(14, min(Kx, 112))
+        r1 = t1.measure(k1, 14, 5)
+        if not r1["ok"]:
+            raise SystemExit("bench self-check failed: config 4 on one GPU")
+        one_us = statistics.median(r1["event_ms"]) * 1e3 / k1
+        fixed1 = statistics.median(r1["run_ms_lead_in_only"]) * 1e3 - r1["lead_in"] * one_us
+        del t1, s1, sc1
+        # what a short wall clock hides: every timed sample is ONE hipGraph replay whose fixed submit cost (~13 us on
+        # ROCm 7.2) is paid once per sample whatever the batch; both speed-ups are reported (DESIGN.md section 6)
+        f.update({"one_gpu_launch_us": round(one_us, 3), "speedup_event": round(one_us / m["launch_us_max"], 3),
+                  "speedup_wall": round((Kx4 * one_us + fixed1) / (m["wall"] * 1e6), 3), "ideal": world})
+        out["s4_strong"] = f
+        sec1, ok1, _, how1 = streamed_time(G4, 4, 112, dev)
+        out["streamed_s4"] = {"global_batch": G4, "share_us_per_step": round(sec_max / ks * 1e6, 3), "share_mode": how,
+                              "one_gpu_us_per_step": round(sec1 / 112 * 1e6, 3), "one_gpu_mode": how1, "ok": bool(ok1),
+                              "speedup": round((sec1 / 112) / (sec_max / ks), 3),
+                              "value": round(G4 / (sec_max / ks), 1)}
+        torch.cuda.empty_cache()
+    group.barrier()
+    return out
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
@@ -494,13 +685,15 @@ def main(argv=None):
     ap.add_argument("--samples", type=int, default=9, help="timed samples of exactly --steps steps each (median reported)")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="graph: the K launches of a sample are one hipGraph replay; eager: K ctypes launches")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
-                    help="N>1: strong = --global-batch games in total (default: BASELINE config 4), weak = --batch per GPU")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N>1: weak (default) = --batch games per GPU, the N=1 workload on every GPU; strong = --global-batch "
+                         "games in total (BASELINE config 4).  The other one is measured as well and reported beside it")
     ap.add_argument("--global-batch", type=int, default=1 << 20, help="games in total under --scaling strong")
     ap.add_argument("--dim", type=int, default=4, help="S of the timed workload (4 = BASELINE config 2 / 4)")
     ap.add_argument("--batch", type=int, default=0, help="games per GPU (default: 65536 for S=4, 8192 for S=16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
+    ap.add_argument("--print-also", action="store_true", help="print the `also` entries as separate lines BEFORE the contract line")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous, shard arithmetic and the JSON line only -- no GPU work (CPU test of the N>1 path)")
     args = ap.parse_args(argv)
@@ -520,29 +713,40 @@ def main(argv=None):
     from mat_mul_amd.sharding import RankGroup
 
     S = args.dim
-    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    scaling = args.scaling if world > 1 else "weak"
     per_gpu_default = {4: 65536, 16: 8192, 25: 4096, 9: 32768}.get(S, 4096)
-    if scaling == "strong" and world > 1:
+    if scaling == "strong":
         G = args.global_batch
     else:
         G = (args.batch or per_gpu_default) * world
     lo, hi = shard_range(G, rank, world)  # contiguous global game ids of this rank
     B = hi - lo
-    if scaling == "strong" and world > 1:
+    if scaling == "strong":
         cfg = f"BASELINE config 4: S={S} int8, {G} games in total sharded over {world} GPUs ({G // world} per GPU)"
     else:
         cfg = (f"BASELINE config {2 if S == 4 else 3 if S == 16 else '-'}: S={S} int8, batch={G // world} independent "
                f"games per GPU")
+    head = {"metric": "env steps/sec (batched games)", "value": None, "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "samples": args.samples, "ms_per_step": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+            "config": {"workload": cfg + "; one in-place tg_step_i8 launch per step", "S": S, "batch_per_gpu": G // world,
+                       "global_batch": G, "launch": args.mode,
+                       "parallelism": f"shard{world} (contiguous game ranges, no collective)"}}
 
     if args.dry_run:
         group = RankGroup("gloo")
         group.barrier()
         (tot,) = group.max_over_ranks(float(hi))
         if rank == 0:
-            print(json.dumps({"metric": "env steps/sec (batched games)", "value": None, "unit": "steps/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "samples": args.samples, "scaling": scaling,
-                              "dry_run": True, "config": {"workload": cfg, "S": S, "global_batch": G,
-                                                          "batch_rank0": B, "last_game_id": int(tot)}}), flush=True)
+            head["dry_run"] = True
+            head["config"].update({"batch_rank0": B, "last_game_id": int(tot)})
+            if world > 1:  # the shard arithmetic of the extras an N>1 run measures (sharded_extras)
+                head["shards"] = {}
+                for key, (g2, s2) in {"s16_weak": (8192 * world, 16), "s16_strong": (8192, 16), "s4_strong": (1 << 20, 4),
+                                      "s4_weak": (65536 * world, 4)}.items():
+                    l2, h2 = shard_range(g2, 0, world)
+                    head["shards"][key] = {"S": s2, "global_batch": g2, "batch_rank0": h2 - l2}
+            print(contract_line(head), flush=True)
         group.close()
         return 0
 
@@ -563,76 +767,61 @@ def main(argv=None):
     group.barrier()
     from mat_mul_amd import _lib  # noqa: F401  (raises if libtensorgame.so or a symbol is missing: no CPU path)
 
-    R = 7 if S == 4 else 8
-    start, sched, _ = make_demo_schedule(B, S, R, dev, 0, lo)
-    tm = StepTimer(start, sched, dev, args.mode)
-    res = tm.measure(args.steps, args.warmup, args.samples, sync=group.barrier)
-    # per rank: the event-timed launch time and the fixed cost of one graph replay; MAX over ranks of both
-    my_launch_us = statistics.median(res["event_ms"]) * 1e3 / args.steps
-    my_fixed_us = statistics.median(res["run_ms_lead_in_only"]) * 1e3 - res["lead_in"] * my_launch_us
-    reduced = group.max_over_ranks(*res["wall_s"], 0.0 if res["ok"] else 1.0, my_launch_us, my_fixed_us)
-    walls, bad, launch_us_max, fixed_us_max = list(reduced[:-3]), reduced[-3], reduced[-2], reduced[-1]
-    if bad:
-        raise SystemExit("bench self-check failed: the state did not return to its start after full cycles")
+    m = sharded_step(group, G, S, dev, args.mode, args.steps, args.warmup, args.samples)
+    res, sched, walls, wall = m["res"], m["sched"], m["walls"], m["wall"]
+    extras = sharded_extras(group, world, dev, args.mode, args.steps, m) if world > 1 and not args.no_also else {}
 
     if rank == 0:
-        wall = statistics.median(walls)
         need = needed_bytes_per_launch(B, S, sched)
         copy = copy_ceiling_gbps(B, S, dev)
         hbm_copy = hbm_copy_ceiling(dev) if world == 1 and not args.no_also else None
-        out = {
-            "metric": "env steps/sec (batched games)", "value": round(G * args.steps / wall, 1), "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "samples": args.samples,
-            "ms_per_step": round(wall * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "i8", "data": "synthetic",
-            "config": {"workload": cfg + "; one in-place tg_step_i8 launch per step",
-                       "S": S, "batch_per_gpu": G // world, "global_batch": G, "launch": args.mode,
-                       "parallelism": f"shard{world} (contiguous game ranges, no collective)",
-                       "timing": f"{args.samples} samples of exactly {args.steps} steps, each bracketed by barrier + "
-                                 f"synchronize, max over ranks per sample, median over samples",
-                       "wall_us_per_sample": [round(w * 1e6, 1) for w in walls]},
-            "roofline": roofline(B, S, args.steps, res["event_ms"], need, copy, res=res, hbm_copy=hbm_copy),
-        }
+        out = dict(head)
+        out.update({"value": round(G * args.steps / wall, 1), "ms_per_step": round(wall * 1e3 / args.steps, 6)})
+        out["config"] = dict(head["config"], timing=f"{args.samples} samples of exactly {args.steps} steps, each bracketed by "
+                             f"barrier + synchronize, max over ranks per sample, median over samples",
+                             wall_us_per_sample=[round(w * 1e6, 1) for w in walls])
+        out["roofline"] = roofline(B, S, args.steps, res["event_ms"], need, copy, res=res, hbm_copy=hbm_copy)
         if world > 1:
-            # what a --steps 20 wall clock hides: every timed sample is ONE hipGraph replay, whose fixed submit cost
-            # (~13 us on ROCm 7.2) is paid once per sample whatever the batch -- so the wall-clock speed-up of a
-            # strong-scaling run understates the kernels'.  Both are reported; the kernels' from HIP events, MAX over ranks.
-            out["per_rank"] = {"event_launch_us_max_over_ranks": round(launch_us_max, 3),
-                               "graph_replay_fixed_cost_us_max_over_ranks": round(fixed_us_max, 2),
-                               "event_steps_per_s": round(G / (launch_us_max * 1e-6), 1),
+            out["per_rank"] = {"event_launch_us_max_over_ranks": round(m["launch_us_max"], 3),
+                               "graph_replay_fixed_cost_us_max_over_ranks": round(m["fixed_us_max"], 2),
+                               "event_steps_per_s": round(G / (m["launch_us_max"] * 1e-6), 1),
                                "wall_us_per_step": round(wall * 1e6 / args.steps, 3)}
-        if world > 1 and scaling == "strong" and not args.no_also:
-            # the same GLOBAL batch on ONE GPU (rank 0 alone, after the timed region): the denominator of the
-            # strong-scaling speedup, measured in the same run
-            s1, sc1, _ = make_demo_schedule(G, S, R, dev, 0, 0)
-            t1 = StepTimer(s1, sc1, dev, args.mode)
-            k1 = max(14, min(args.steps, 112))
-            r1 = t1.measure(k1, 14, 5)
-            w1 = statistics.median(r1["wall_s"])
-            out["single_gpu_same_global_batch"] = {
-                "ok": r1["ok"], "value": round(G * k1 / w1, 1), "unit": "steps/s", "steps": k1,
-                "roofline": roofline(G, S, k1, r1["event_ms"], needed_bytes_per_launch(G, S, sc1))}
-            one_us = out["single_gpu_same_global_batch"]["roofline"]["avg_launch_us"]
-            fixed1 = statistics.median(r1["run_ms_lead_in_only"]) * 1e3 - r1["lead_in"] * one_us
-            # the driver's own clock sees (K launches + one replay) per sample on both sides of the ratio
-            out["speedup_vs_single"] = {
-                "event": round(one_us / launch_us_max, 3),
-                "wall_at_these_steps": round((args.steps * one_us + fixed1) / (wall * 1e6), 3),
-                "wall_model": "T1 = steps x the single-GPU launch time + its replay cost, over the measured N-GPU wall time of a sample",
-                "single_gpu_launch_us": one_us, "single_gpu_replay_fixed_cost_us": round(fixed1, 2),
-                "ideal": world}
-            del t1, s1, sc1
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(G, S)
+            out.update(extras)
+        if not args.no_cpu_baseline:  # rank 0, after every timed region; a shorter sample when other ranks wait for it
+            out["cpu_baseline"] = cpu_baseline(G // world, S, budget_s=12.0 if world == 1 else 5.0, sweep_s=1.0 if world == 1 else 0.4)
+        also = []
         if world == 1 and not args.no_also:
-            out["also"] = also_lines(S, G, dev, args.mode, hbm_copy)
+            also = also_lines(S, G, dev, args.mode, hbm_copy)
             # BASELINE's metric names S=4 and S=16: surface config 3 at the top level as well
-            for a3 in out["also"]:
-                if a3["workload"].startswith("S=16 batch=8192 (BASELINE config 3)"):
+            for a3 in also:
+                wl = a3["workload"]
+                if wl.startswith("S=16 batch=8192 (BASELINE config 3)"):
                     out["value_s16"] = a3["value"]
                     out["ms_per_step_s16"] = round(a3["roofline"]["avg_launch_us"] * 1e-3, 6)
                     out["roofline_s16"] = a3["roofline"]
-        print(json.dumps(out), flush=True)
+                elif wl.startswith("S=4 batch=131072 (BASELINE config 4 per-GPU share"):
+                    out.setdefault("cfg4_one_gpu", {})["share_of_8_launch_us"] = a3["roofline"]["avg_launch_us"]
+                elif wl.startswith("S=4 batch=1048576 (BASELINE config 4 on ONE GPU"):
+                    out.setdefault("cfg4_one_gpu", {})["whole_launch_us"] = a3["roofline"]["avg_launch_us"]
+                elif wl.startswith("STREAMED tg_step_stream_i8: S=4 batch=131072"):
+                    out.setdefault("cfg4_one_gpu", {})["streamed_share_of_8_us_per_step"] = a3["us_per_step"]
+                elif wl.startswith("STREAMED tg_step_stream_i8: S=4 batch=1048576"):
+                    out.setdefault("cfg4_one_gpu", {})["streamed_whole_us_per_step"] = a3["us_per_step"]
+                elif wl.startswith("GENERATOR tg_gen_demos_i8") and "basis" not in wl:
+                    out["generator_cfg5"] = {"us_per_launch": a3["us_per_launch"], "demos_per_s": a3["value"],
+                                             "bound": a3.get("bound"), "valu_issue_frac": a3.get("valu_issue_frac")}
+            c4 = out.get("cfg4_one_gpu", {})
+            if "share_of_8_launch_us" in c4 and "whole_launch_us" in c4:  # what 8 GPUs can reach on kernel time
+                c4["predicted_speedup_8gpu_event"] = round(c4["whole_launch_us"] / c4["share_of_8_launch_us"], 3)
+            if "streamed_share_of_8_us_per_step" in c4 and "streamed_whole_us_per_step" in c4:
+                c4["predicted_speedup_8gpu_streamed"] = round(c4["streamed_whole_us_per_step"] / c4["streamed_share_of_8_us_per_step"], 3)
+            out["also_ok"] = {"entries": len(also), "failed": [a["workload"][:60] for a in also if not a.get("ok", True)]}
+        if also or world > 1:
+            out["also_file"] = write_side_file(out, also)
+        if args.print_also:
+            for a in also:
+                print(json.dumps(a), flush=True)
+        print(contract_line(out), flush=True)   # LAST line of stdout
     group.barrier()
     group.close()
     return 0
@@ -698,53 +887,20 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
                      "us_per_launch": round(sec * 1e6, 2), "GBps": round(nbytes / sec / 1e9, 1)})
     # the streamed stepper (its own entry and metric): K steps in ONE resident launch, the state stays in registers,
     # per step poll + 12 token bytes in + state and done written through + a progress word per wavefront
-    for (s2, b2, k2, r2) in [(4, 65536, 1008, 7), (4, 131072, 504, 7), (16, 8192, 512, 8), (25, 4096, 256, 8), (4, 1 << 20, 112, 7),
-                             (25, 32768, 64, 8)]:  # (the last two: BASELINE configs 4 and 5 whole on one GPU, units in rounds)
-        tok, tgt = ops.gen_demos(b2, s2, r2, dev, seed=4)
-        cyc = torch.cat([tok, tok], dim=1)
-        cyc[:, r2:, :s2] = 2 - cyc[:, r2:, :s2]                  # the same terms with u negated: period 14
-        acts = cyc.permute(1, 0, 2).contiguous().repeat(k2 // (2 * r2), 1, 1)   # (K, B, 12) step-major
-        st2 = ops.alloc_states(b2, s2, dev)
-        st2.copy_(tgt)
-        dn = torch.empty((k2, b2), dtype=torch.uint8, device=dev)
-        try:
-            n_units, gpw = ops.step_stream_layout(b2, s2, dev)
-            ready = torch.ones(k2, dtype=torch.int32, device=dev)    # pre-set: the producer is never the bottleneck
-        except RuntimeError:  # (TensorGameError) beyond the resident batch (S=4): no ready words, units of 16 games in rounds
-            n_units, gpw, ready = -(-b2 // 16), 16, None
-        prog = torch.zeros(n_units, dtype=torch.int32, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
-        fn = lambda: ops.step_stream(st2, acts, done=dn, ready=ready, progress=prog, status=status)
-        fn()
-        torch.cuda.synchronize(dev)
-        ts = []
-        for _ in range(5):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn()
-            e1.record()
-            torch.cuda.synchronize(dev)
-            ts.append(e0.elapsed_time(e1) * 1e-3)
-        sec = statistics.median(ts)
-        ok = bool(torch.equal(st2, tgt)) and int(status[0]) == 0 and bool((prog == k2).all()) \
-            and bool(dn[r2 - 1].all()) and not bool(dn[0].all())
+    for (s2, b2, k2) in [(4, 65536, 1008), (4, 131072, 504), (16, 8192, 512), (25, 4096, 256), (4, 1 << 20, 112),
+                         (25, 32768, 64)]:  # (the last two: BASELINE configs 4 and 5 whole on one GPU, units in rounds)
+        sec, ok, gpw, how = streamed_time(b2, s2, k2, dev)
         # per step: tokens in, done out, and the state written through: the whole game once per block of steps
         if s2 == 4:   # the state leaves once per block of D steps (D = 8 / 4 / 2 for 16 / 32 / more games per wavefront)
             moved = b2 * (3 * s2 + 1) + b2 * s2 ** 3 / {16: 8, 32: 4}.get(gpw, 2)
-        elif s2 == 25:  # whole games once per block of 8 steps
-            moved = b2 * (3 * s2 + 1) + b2 * s2 ** 3 / 8
-        else:           # S=16: whole games once per block of 8 steps
+        else:         # S=16 / S=25: whole games once per block of 8 steps
             moved = b2 * (3 * s2 + 1) + b2 * s2 ** 3 / 8
         also.append({"workload": f"STREAMED tg_step_stream_i8: S={s2} batch={b2}, K={k2} steps in ONE launch, actions "
-                                 f"consumed step by step ({'ready words pre-set' if ready is not None else 'no ready words: beyond the resident batch, units of 16 games in rounds'}), "
+                                 f"consumed step by step ({'ready words pre-set' if how == 'ready' else 'no ready words: beyond the resident batch, the units run in rounds'}), "
                                  f"progress published per wavefront; not the single-step metric",
                      "ok": ok, "value": round(b2 * k2 / sec, 1), "unit": "steps/s", "us_per_step": round(sec / k2 * 1e6, 3),
-                     "GBps_moved": round(moved * k2 / sec / 1e9, 1),
-                     "frac_of_hbm_peak_moved_bytes": round(moved * k2 / sec / 1e9 / HBM_PEAK_GBS, 4),
-                     "launch_per_step_us": None,
-                     "note": "bytes moved per step: tokens in, done out, the game once per block of released steps; the "
-                             "state is not re-read, it lives in registers"})
-        del acts, dn
+                     "games_per_wavefront": gpw, "GBps_moved": round(moved * k2 / sec / 1e9, 1),
+                     "frac_of_hbm_peak_moved_bytes": round(moved * k2 / sec / 1e9 / HBM_PEAK_GBS, 4)})
     # BASELINE config 5's generator (per-GPU share: 4 096 demos, S=25, R=64), with and without the change
     # of basis; bytes = target + tokens written (S^3 + 3SR per demo); replayed as a hipGraph
     for with_basis in (False, True):

@@ -39,8 +39,9 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3 /* 2: the generator draws 16-bit uniforms (8 per Philox block); tg_copy_i8.  3 (additions only, round 3):
-                          * tg_step_tracked_i8, tg_step_emit, tg_expand_keyed_i8, tg_seen_u64 */
+#define TG_ABI_VERSION 4 /* 2: the generator draws 16-bit uniforms (8 per Philox block); tg_copy_i8.  3 (additions only, round 3):
+                          * tg_step_tracked_i8, tg_step_emit, tg_expand_keyed_i8, tg_seen_u64.  4 (round 4): tg_step_stream_capacity;
+                          * tg_step_stream_i8 refuses ready words beyond the resident batch at S = 16 / 25 and waits 1.0 s, in time */
 #define TG_MAX_S 32
 #define TG_MAX_VALUES 8 /* categories of the factor distribution */
 
@@ -77,8 +78,8 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
  * tg_done_i8 computes it, a reset knows it) and the step updates it, so only the chunks whose rows have u_i v_j != 0 are
  * loaded and stored, and done[b] = (nnz[b] == 0).  Same state, done and overflow as tg_step_i8(state, state, ...).
  * Replaces get_child_states k=1,T=1 + tensor_factorized per game (act.py:266-275, utils.py:181-188) for an env that keeps
- * its games resident.  S = 25 takes the sparse kernel (aligned states); every other shape runs tg_step_i8 + the count
- * inside this call. */
+ * its games resident.  S = 16 and S = 25 take the sparse kernels (aligned states; S = 25 from 2 048 games on, below that the
+ * full step with a count); every other shape runs tg_step_i8 + the count inside this call. */
 int tg_step_tracked_i8(int8_t* state, const int8_t* actions, int32_t* nnz, uint8_t* done, uint8_t* overflow,
                        int64_t B, int S, int64_t game_stride_bytes, int shift, tg_stream_t stream);
 
@@ -108,14 +109,17 @@ int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* act
  *   and done[0..k] of unit u's games are visible to other agents (write-through stores, drained).  The word is
  *   non-decreasing, ends at K, and is stored before the unit waits for a ready word that is not set yet; between two
  *   stores of it the state in memory is not defined.
- *   status: uint32 (1) or NULL, set to 1 if a wavefront gave up waiting for a ready word (bounded spin, ~1 s).
+ *   status: uint32 (1) or NULL, set to 1 if a wavefront gave up waiting for a ready word: it waits 1.0 s (measured on the
+ *   chip's 100 MHz real-time counter, whatever the clocks do), then leaves its games at the last step it published.
  * No wavefront ever waits for another one, so the launch itself cannot deadlock; a producer that waits for the WHOLE
  * batch before releasing the next step additionally needs every unit resident at once: at S = 4
  * tg_step_stream_layout chooses the games per wavefront so that this holds and refuses batches beyond what the
  * device keeps resident (about 4.5e5 games on the 256 CUs of an MI355X; with ready == NULL tg_step_stream_i8 takes any B: units
  * of 16 games run in rounds, progress -- if given -- has (B + 15) / 16 words); S = 16 (one wavefront per game, the 4 KiB of
- * a game in registers) holds 32 games per CU = 8 192 on 256 CUs, beyond that the units run in rounds; S = 25 (one wavefront per game, the game's 15 625
- * bytes in registers) holds 16 games per CU = 4 096 on 256 CUs.  S = 4, S = 16 and S = 25 in this build
+ * a game in registers) holds 32 games per CU = 8 192 on 256 CUs; S = 25 (one wavefront per game, the game's 15 625
+ * bytes in registers) holds 16 games per CU = 4 096 on 256 CUs.  Beyond these (tg_step_stream_capacity) S = 16 / 25 run
+ * their units in rounds too, with ready == NULL only: with ready words the call is refused (TG_ERR_UNSUPPORTED) -- a later
+ * round would start only when an earlier one has finished all K steps.  S = 4, S = 16 and S = 25 in this build
  * (TG_ERR_UNSUPPORTED otherwise), states 16-byte aligned, actions 4-byte aligned (S = 16: 16-byte).  This is a separate entry with its own metric: the single-step figures of tg_step_i8
  * never include it. */
 int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8_t* overflow,
@@ -123,6 +127,9 @@ int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8
                       int64_t game_stride_bytes, int shift, tg_stream_t stream);
 /* n_units (wavefronts) and games_per_unit of tg_step_stream_i8 for B games (host call, no device work). */
 int tg_step_stream_layout(int64_t B, int S, int64_t* n_units, int* games_per_unit);
+/* The largest B tg_step_stream_i8 accepts together with ready words on the current device: every unit resident at once
+ * (host call, no device work; from the occupancy of the stepper's kernels on this device). */
+int tg_step_stream_capacity(int S, int64_t* games);
 
 /* k children per parent: state_out[b*k+i] = state_in[b] - tensor(actions[b][i]).
  * done, changed, overflow: uint8 (B,k); changed[b][i] = child differs from parent (the per-game

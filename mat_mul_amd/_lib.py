@@ -13,7 +13,7 @@ AB_VARIANT = _VARIANT in ("ab", "stamps")
 LIB_PATH = Path(__file__).resolve().parent / "lib" / {"ab": "libtensorgame_ab.so", "stamps": "libtensorgame_stamps.so"}.get(
     _VARIANT, "libtensorgame.so")
 
-TG_ABI_VERSION = 3
+TG_ABI_VERSION = 4
 TG_MAX_S = 32
 TG_MAX_VALUES = 8
 TG_MAX_ACTIONS = 4096
@@ -39,6 +39,7 @@ SIGNATURES = {
     "tg_step_many_i8": [_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _p],
     "tg_step_stream_i8": [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _p],
     "tg_step_stream_layout": [_i64, _i, _p, _p],
+    "tg_step_stream_capacity": [_i, _p],
     "tg_expand_i8": [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i, _p],
     "tg_expand_keyed_i8": [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i, _p],
     "tg_copy_i8": [_p, _p, _i64, _i, _i64, _i64, _p],

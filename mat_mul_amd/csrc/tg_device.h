@@ -138,9 +138,7 @@ __device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t 
   return d;
 }
 
-// ---- the factor distribution of the generator (host-filled, passed by value) ----------------
-// The basis sampler draws 32-bit uniforms against `thr`.  The factor generator draws SIXTEEN-bit uniforms,
-// eight per Philox block: a draw d16 selects val[#{t : d16 * 2^16 >= thr[t]}], i.e. d16 is compared with
+// ---- wavefront scans / sums, LDS-only barrier ---------------------------------------------------
 // inclusive prefix sum over the 64 lanes of a wavefront, all in the VALU (DPP row shifts and row broadcasts)
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
   x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false);  // row_shr:1
@@ -165,6 +163,9 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ---- the factor distribution of the generator (host-filled, passed by value) ----------------
+// The basis sampler draws 32-bit uniforms against `thr`.  The factor generator draws SIXTEEN-bit uniforms,
+// eight per Philox block: a draw d16 selects val[#{t : d16 * 2^16 >= thr[t]}], i.e. d16 is compared with
 // thr16[t] = ceil(thr[t] / 2^16) in [0, 65536].  For the packed evaluation (two draws per dword) the
 // thresholds that are always true (thr16 == 0) are folded into `base16` and those never true (65536) are
 // dropped: value = base + sum_{t < nthr} [d16 >= c16[t] + 1] * delta16[t], all int16 replicated in both halves.

@@ -958,7 +958,7 @@ struct StreamArgs {
   int64_t stride;
   int K;
   int shift;
-  uint32_t spin_limit;
+  uint32_t wait_ticks;  // how long a wavefront waits for a ready word: ticks of s_memrealtime (100 MHz)
 };
 
 template <int NG>
@@ -1040,12 +1040,14 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
     const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     return released(v, kp);
   };
-  auto wait_released = [&](int kp) {  // every spin is bounded; 0 = gave up
-    uint32_t spins = 0;
+  auto wait_released = [&](int kp) {  // bounded in TIME (a.wait_ticks); 0 = gave up
+    uint64_t t0 = 0;  // the first miss starts the clock: s_memrealtime, 100 MHz, the same counter on every XCD
     for (;;) {
       const int n = poll_now(kp);
       if (n) return n;
-      if (++spins >= a.spin_limit) {
+      const uint64_t now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now | 1u;
+      if (now - t0 >= a.wait_ticks) {
         if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return 0;
       }
@@ -1464,13 +1466,15 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
     const unsigned long long m = __ballot(lane < D && kp + lane < a.K && v != 0);
     return static_cast<int>(__builtin_ctzll(~m));
   };
-  auto wait_released = [&](int kp) {  // every spin is bounded; 0 = gave up
-    uint32_t spins = 0;
+  auto wait_released = [&](int kp) {  // bounded in TIME (a.wait_ticks); 0 = gave up
+    uint64_t t0 = 0;  // the first miss starts the clock: s_memrealtime, 100 MHz, the same counter on every XCD
     for (;;) {
       const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       const int n = released(v, kp);
       if (n) return n;
-      if (++spins >= a.spin_limit) {
+      const uint64_t now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now | 1u;
+      if (now - t0 >= a.wait_ticks) {
         if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return 0;
       }
@@ -1645,9 +1649,10 @@ __global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
   // kernel runs at its register limit, and a register that an asm load has yet to fill may be copied or spilled by hipcc
   // before the data is there -- LDS cannot.  Counted waits as in the other steppers; M0 (the DMA's LDS base) is saved
   // and restored inside the statement.
-  // The DMA moves ALIGNED dwords: a step's 75 token bytes start at any byte address A, so lane l < 20 asks for dword l of
-  // [A - (A & 3), ...) and the step reads its token i at byte (A & 3) + i of the row (actions is 4-byte aligned: nothing in
-  // front of the buffer is touched, and behind it at most the rest of the dword that holds the last token).
+  // The DMA moves ALIGNED dwords: a step's 75 token bytes start at any byte address A, so lane l < nd asks for dword l of
+  // [A - (A & 3), ...), nd = ceil(((A & 3) + 75) / 4) = 19 or 20, and the step reads its token i at byte (A & 3) + i of the row
+  // (actions is 4-byte aligned: nothing in front of the buffer is touched, and behind it at most the rest of the dword that
+  // holds the last token -- a fixed 20 dwords would ask for [end, end + 4) of the last game's last step when A & 3 <= 1).
   auto tokens_of = [&](int k) { return a.actions + (static_cast<int64_t>(k) * a.B + g) * 75; };
   auto dma = [&](const void* base, uint32_t voff, const void* lds_row) {
     const uint32_t dst = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_row));
@@ -1655,13 +1660,14 @@ __global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3 sc1\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(dst), "v"(voff), "s"(base) : "memory");
   };
-  const uint32_t tk_off = lane < 20 ? 4u * lane : 0u;
   auto request = [&](int kb, int kp, bool with_poll) {
     if (with_poll) dma(a.ready + kp, (lane < D && kp + lane < a.K) ? 4u * lane : 0u, &pollbuf[wave][0]);
 #pragma unroll 1
     for (int d = 0; d < D; ++d) {
       const uintptr_t A = reinterpret_cast<uintptr_t>(tokens_of(kb + d < a.K ? kb + d : a.K - 1));
-      dma(reinterpret_cast<const void*>(A & ~static_cast<uintptr_t>(3)), tk_off, &tokbuf[wave][d][0]);
+      const uint32_t nd = (static_cast<uint32_t>(A & 3) + 75u + 3u) >> 2;  // dwords that hold this step's 75 tokens
+      dma(reinterpret_cast<const void*>(A & ~static_cast<uintptr_t>(3)), static_cast<uint32_t>(lane) < nd ? 4u * lane : 0u,
+          &tokbuf[wave][d][0]);
     }
   };
   auto arrived = [&]() { __builtin_amdgcn_wave_barrier(); };  // behind the counted wait: the rows are in LDS
@@ -1669,13 +1675,15 @@ __global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
     const unsigned long long m = __ballot(lane < D && kp + lane < a.K && v != 0);
     return static_cast<int>(__builtin_ctzll(~m));
   };
-  auto wait_released = [&](int kp) {  // every spin is bounded; 0 = gave up
-    uint32_t spins = 0;
+  auto wait_released = [&](int kp) {  // bounded in TIME (a.wait_ticks); 0 = gave up
+    uint64_t t0 = 0;  // the first miss starts the clock: s_memrealtime, 100 MHz, the same counter on every XCD
     for (;;) {
       const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       const int n = released(v, kp);
       if (n) return n;
-      if (++spins >= a.spin_limit) {
+      const uint64_t now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now | 1u;
+      if (now - t0 >= a.wait_ticks) {
         if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return 0;
       }
@@ -2489,34 +2497,62 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
   return launch_apply<tg::STEP>("tg_step_i8", a, static_cast<hipStream_t>(stream));
 }
 
+constexpr uint32_t kStreamWaitTicks = 100000000u;  // 1.0 s of s_memrealtime (100 MHz)
+
+// Units of each streamed-stepper variant this device keeps resident at once (from the occupancy of ITS kernel on THIS device).
+// S = 4: NG games x 16 per wavefront (NG = 1, 2 run 8 workgroups per CU, NG = 4 seven, NG = 8 three on gfx950).
+static int64_t stream_units_resident(int S, int ng) {
+  static OccupancySlots occ1, occ2, occ4, occ8, occ16, occ25;
+  const int64_t cus = device_cu_count();
+  if (S == 16) return cus * 4 * resident_per_cu(tg::s16_stream_kernel, 0, occ16);
+  if (S == 25) return cus * 4 * resident_per_cu(tg::s25_stream_kernel, 0, occ25);
+  switch (ng) {
+    case 1: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<1>, 0, occ1);
+    case 2: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<2>, 0, occ2);
+    case 4: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<4>, 0, occ4);
+    default: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<8>, 0, occ8);
+  }
+}
+
+/* the largest batch tg_step_stream_i8 takes WITH ready words: every unit resident at once on the current device */
+int tg_step_stream_capacity(int S, int64_t* games) {
+  if (S != 4 && S != 16 && S != 25)
+    return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_capacity: S=%d (the streamed stepper is built for S=4, S=16 and S=25)", S);
+  if (!games) return fail(TG_ERR_INVALID, "tg_step_stream_capacity: null pointer");
+  int64_t most = 0;
+  if (S == 4) {
+    for (int ng = 1; ng <= 8; ng *= 2) {
+      const int64_t c = stream_units_resident(4, ng) * 16 * ng;
+      most = c > most ? c : most;
+    }
+  } else {
+    most = stream_units_resident(S, 1);  // one wavefront per game
+  }
+  *games = most;
+  return TG_OK;
+}
+
 /* units (wavefronts) and games per unit of tg_step_stream_i8 for a batch of B games, or a negative TG_ERR_* */
 int tg_step_stream_layout(int64_t B, int S, int64_t* n_units, int* games_per_unit) {
   if (B < 0) return fail(TG_ERR_INVALID, "tg_step_stream_layout: B < 0");
   if (S != 4 && S != 16 && S != 25)
     return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: S=%d (the streamed stepper is built for S=4, S=16 and S=25)", S);
-  if (S == 16 || S == 25) {  // (S = 25: a wavefront per game too, 16 per CU resident: 4 096 games on 256 CUs)  // one wavefront per game; 32 wavefronts per CU are resident at once (8192 games on 256 CUs)
+  if (S == 16 || S == 25) {  // one wavefront per game at any B (beyond tg_step_stream_capacity the units run in rounds: no ready words)
     if (n_units) *n_units = B;
     if (games_per_unit) *games_per_unit = 1;
     return TG_OK;
   }
-  // S = 4: every wavefront must be resident at once when the producer waits for the whole batch.  How many a CU holds
-  // depends on the variant's registers (NG games x 16 per wavefront: NG = 1, 2 run 8 workgroups per CU, NG = 4 seven,
-  // NG = 8 three on gfx950), so the cap is taken per variant from the occupancy of ITS kernel on THIS device; the
-  // smallest NG whose units all fit is chosen.
-  static OccupancySlots occ1, occ2, occ4, occ8;
-  const int64_t cus = device_cu_count();
-  const int64_t cap[4] = {cus * 4 * resident_per_cu(tg::s4_stream_kernel<1>, 0, occ1), cus * 4 * resident_per_cu(tg::s4_stream_kernel<2>, 0, occ2),
-                          cus * 4 * resident_per_cu(tg::s4_stream_kernel<4>, 0, occ4), cus * 4 * resident_per_cu(tg::s4_stream_kernel<8>, 0, occ8)};
+  // S = 4: every wavefront must be resident at once when the producer waits for the whole batch; the smallest NG whose
+  // units all fit is chosen.
   int64_t most = 0;
-  for (int t = 0; t < 4; ++t) {
-    const int ng = 1 << t;
-    const int64_t units = (B + 16 * ng - 1) / (16 * ng);
-    if (units <= cap[t]) {
+  for (int ng = 1; ng <= 8; ng *= 2) {
+    const int64_t units = (B + 16 * ng - 1) / (16 * ng), cap = stream_units_resident(4, ng);
+    if (units <= cap) {
       if (n_units) *n_units = units;
       if (games_per_unit) *games_per_unit = 16 * ng;
       return TG_OK;
     }
-    most = cap[t] * 16 * ng > most ? cap[t] * 16 * ng : most;
+    most = cap * 16 * ng > most ? cap * 16 * ng : most;
   }
   return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: B=%lld exceeds the %lld games this device keeps resident at once",
               (long long)B, (long long)most);
@@ -2539,6 +2575,13 @@ int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8
     units = (B + 15) / 16;
     gpu_ = 16;
   }
+  // S = 16 / 25 beyond the resident batch run in rounds as well -- and with ready words a producer that releases step k+1
+  // only once EVERY unit has published k would never see the later rounds start (each would wait out its whole bound and
+  // leave the games at different steps): refused, as tg_step_stream_layout refuses it at S = 4
+  if (ready && S != 4 && units > stream_units_resident(S, 1))
+    return fail(TG_ERR_UNSUPPORTED, "%s: B=%lld exceeds the %lld games of S=%d this device keeps resident at once; with ready "
+                "words every unit must be resident (tg_step_stream_capacity) -- pass ready = NULL to run the batch in rounds",
+                fn, (long long)B, (long long)stream_units_resident(S, 1), S);
   // (a single game has no stride to speak of; S = 25 reads the 16-byte chunk that holds the game's last byte: it lies inside
   // the last game's final aligned 16 bytes, and only the game's own 9 bytes of it are ever written)
   if (!aligned16(state) || (game_stride_bytes % 16 != 0 && B > 1) || !(S == 16 ? aligned16(actions) : aligned4(actions)) ||
@@ -2547,7 +2590,7 @@ int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8
     return fail(TG_ERR_UNSUPPORTED, "%s: needs 16-byte aligned states, aligned actions (4 bytes at S=4, 16 at S=16), B*stride and K*B < 2^31, |shift| <= 127", fn);
   if ((ready && (reinterpret_cast<uintptr_t>(ready) & 3)) || (progress && (reinterpret_cast<uintptr_t>(progress) & 3)))
     return fail(TG_ERR_INVALID, "%s: ready / progress must be 4-byte aligned", fn);
-  tg::StreamArgs a{state, actions, done, overflow, ready, progress, status, B, game_stride_bytes, K, shift, 1u << 22};
+  tg::StreamArgs a{state, actions, done, overflow, ready, progress, status, B, game_stride_bytes, K, shift, kStreamWaitTicks};
   const unsigned grid = static_cast<unsigned>((units + 3) / 4);
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();

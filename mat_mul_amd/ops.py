@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import TG_MAX_ACTIONS, TG_MAX_S, TG_MAX_VALUES, TensorGameError, call
 
 __all__ = [
-    "step", "step_tracked", "copy_states", "prepare_step", "step_many", "step_stream", "step_stream_layout", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
+    "step", "step_tracked", "copy_states", "prepare_step", "step_many", "step_stream", "step_stream_layout", "step_stream_capacity", "expand", "done", "reset_matmul", "reset_broadcast", "gen_from_factors",
     "gen_demos", "sample_basis", "change_basis", "as_tokens", "categorical_thresholds",
     "alloc_states", "alloc_ring", "emit_frames", "step_emit", "state_hash", "slice_rank", "alloc_seen_table", "seen",
 ]
@@ -206,6 +206,14 @@ def step_stream_layout(B: int, S: int, device=None) -> Tuple[int, int]:
     with torch.cuda.device(torch.device(device) if device is not None else torch.cuda.current_device()):
         call("tg_step_stream_layout", B, S, C.byref(n), C.byref(g))
     return int(n.value), int(g.value)
+
+
+def step_stream_capacity(S: int, device=None) -> int:
+    """The largest batch ``step_stream`` takes together with ready words on this device (every unit resident at once)."""
+    n = C.c_int64(0)
+    with torch.cuda.device(torch.device(device) if device is not None else torch.cuda.current_device()):
+        call("tg_step_stream_capacity", S, C.byref(n))
+    return int(n.value)
 
 
 def step_stream(state, actions, done=None, overflow=None, ready=None, progress=None, status=None, shift: int = 1):

@@ -22,12 +22,12 @@ def declared_symbols(ab=False):
 
 def test_header_symbols_all_exported():
     syms = declared_symbols()
-    assert len(syms) == 24
+    assert len(syms) == 25
     assert sorted(_lib.SIGNATURES) == syms                 # the ctypes table covers the header exactly
     lib = C.CDLL(str(_lib.LIB_PATH))
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.tg_abi_version() == 3
+    assert lib.tg_abi_version() == 4
     # the A/B variant exports exactly the same entries (it differs only by its environment switches)
     from mat_mul_amd import build
     assert declared_symbols(ab=True) == syms

@@ -88,25 +88,112 @@ def test_stale_traffic_entry_is_omitted(bench):
     assert bench.measured_traffic(65536, 4, "tg::some_other_kernel<0>") == (None, None)
 
 
-def test_self_launch_two_ranks_dry_run(tmp_path):
+def _last_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert lines and lines[-1].startswith("{"), stdout[-500:]     # the contract line is the LAST line of stdout
+    return lines[-1]
+
+
+def test_self_launch_two_ranks_dry_run(tmp_path, bench):
     """`python bench.py --gpus 2` with no launcher in the environment starts its two ranks itself and relays
-    rank 0's line (dry run: rendezvous over gloo + shard arithmetic, no GPU)."""
+    rank 0's line (dry run: rendezvous over gloo + shard arithmetic, no GPU).  Default at N>1: weak scaling of the
+    N=1 workload (65 536 games per GPU); the line also names the shards of the extras an N>1 run measures."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "1"
     res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"],
                          env=env, capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert res.returncode == 0, res.stderr[-3000:]
-    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    line = _last_line(res.stdout)
+    assert len(line) < bench.MAX_LINE_BYTES
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["scaling"] == "strong"
-    assert out["config"]["global_batch"] == 1 << 20 and out["config"]["batch_rank0"] == 1 << 19
-    assert out["config"]["last_game_id"] == 1 << 20 and "config 4" in out["config"]["workload"]
-    # weak scaling on request: 65 536 games per GPU
-    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--scaling", "weak", "--dry-run"],
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 2 * 65536 and out["config"]["batch_rank0"] == 65536
+    assert out["config"]["last_game_id"] == 2 * 65536 and "config 2" in out["config"]["workload"]
+    sh = out["shards"]
+    assert sh["s16_weak"] == {"S": 16, "global_batch": 16384, "batch_rank0": 8192}
+    assert sh["s16_strong"] == {"S": 16, "global_batch": 8192, "batch_rank0": 4096}
+    assert sh["s4_strong"] == {"S": 4, "global_batch": 1 << 20, "batch_rank0": 1 << 19}
+    # strong scaling on request: BASELINE config 4, 2^20 games in total
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--scaling", "strong", "--dry-run"],
                          env=env, capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert res.returncode == 0, res.stderr[-3000:]
-    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
-    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 2 * 65536
+    out = json.loads(_last_line(res.stdout))
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 1 << 20 and out["config"]["batch_rank0"] == 1 << 19
+    assert "config 4" in out["config"]["workload"]
+
+
+def _full_object(bench, world):
+    """A headline object as main() assembles it, from canned numbers, with every optional field present and the
+    longest kernel names / workload strings the bench can produce."""
+    res = {"lead_in": 8, "run_ms_with_lead_in": [0.08] * 9, "run_ms_lead_in_only": [0.03] * 9}
+    B = 65536
+    r4 = bench.roofline(B, 4, 20, [2.3e-3 * 20] * 9, None, (4200.123, 2.234), res=res, hbm_copy=(6712.3, 640.12))
+    r16 = bench.roofline(1 << 17, 16, 512, [98.24e-3 * 512] * 5, 612345678.9, (5321.1, 201.2), hbm_copy=(6712.3, 640.12))
+    assert r16["kernel"] == "tg::s16_step_kernel<0, true, true, true>"
+    full = {"metric": "env steps/sec (batched games)", "value": 19612345678.9, "unit": "steps/s", "n_gpus": world, "steps": 2016,
+            "warmup": 224, "samples": 9, "ms_per_step": 0.003338, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+            "config": {"workload": "BASELINE config 4: S=4 int8, 1048576 games in total sharded over 8 GPUs (131072 per GPU); one "
+                                   "in-place tg_step_i8 launch per step", "S": 4, "batch_per_gpu": B, "global_batch": B * world,
+                       "launch": "graph", "parallelism": f"shard{world} (contiguous game ranges, no collective)",
+                       "timing": "x" * 300, "wall_us_per_sample": [66.123] * 9},
+            "roofline": r4,
+            "cpu_baseline": {"value": 5412345.6, "unit": "steps/s", "cores": 16, "kind": "port", "c_int8_port_1thread_steps_per_s": 1.0,
+                             "sample": "63 batched steps of the same workload (B=65536, S=4) in 12.0 s", "sample_detail": "y" * 400,
+                             "host_cpus_available": 256, "per_game_loop_steps_per_s": 19812.3},
+            "value_s16": 1540819744.3, "ms_per_step_s16": 0.00526, "roofline_s16": r16,
+            "also_file": "bench_also.json", "also_ok": {"entries": 48, "failed": []}}
+    fig = {"global_batch": 1 << 20, "batch_per_gpu": 131072, "value": 241234567890.1, "ms_per_step": 0.004351,
+           "launch_us": 3.335, "event_steps_per_s": 314123456789.0}
+    if world > 1:
+        full["per_rank"] = {"event_launch_us_max_over_ranks": 2.4}
+        full["s16_strong"] = dict(fig)
+        full["s4_weak"] = dict(fig)
+        full["s4_strong"] = dict(fig, one_gpu_launch_us=21.523, speedup_event=6.453, speedup_wall=6.012, ideal=8)
+        full["streamed_s4"] = {"global_batch": 1 << 20, "share_us_per_step": 0.805, "share_mode": "ready", "one_gpu_us_per_step": 5.221,
+                               "one_gpu_mode": "rounds", "ok": True, "speedup": 6.486, "value": 1302579710144.9}
+    else:
+        full["cfg4_one_gpu"] = {"share_of_8_launch_us": 3.335, "whole_launch_us": 21.523, "streamed_share_of_8_us_per_step": 0.805,
+                                "streamed_whole_us_per_step": 5.221, "predicted_speedup_8gpu_event": 6.453,
+                                "predicted_speedup_8gpu_streamed": 6.486}
+        full["generator_cfg5"] = {"us_per_launch": 26.03, "demos_per_s": 157536950.5, "bound": "valu", "valu_issue_frac": 0.5774}
+    return full
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_contract_line_is_short_and_complete(bench, world):
+    """round 3's line was 28.7 KB (40 `also` entries inline), the driver kept a tail of it and parsed nothing.
+    The line is now built by contract_line(): contract fields + numeric roofline / cpu_baseline / S=16 / sharded objects,
+    bounded at 4 KB; prose, sample lists and `also` go to bench_also.json."""
+    full = _full_object(bench, world)
+    line = bench.contract_line(full)
+    assert len(line) < bench.MAX_LINE_BYTES == 4096 and "\n" not in line
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "value_s16", "ms_per_step_s16", "roofline_s16"):
+        assert k in out, k
+    assert set(out["roofline"]) <= set(bench.ROOFLINE_KEYS) and set(out["roofline_s16"]) <= set(bench.ROOFLINE_KEYS)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in out["roofline"] and k in out["roofline_s16"]
+    assert abs(out["roofline"]["frac"] - out["roofline"]["achieved"] / out["roofline"]["peak"]) < 1e-4
+    assert set(out["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample", "host_cpus_available", "per_game_loop_steps_per_s"}
+    assert "timing" not in out["config"] and "wall_us_per_sample" not in out["config"] and "workload" in out["config"]
+    assert "per_rank" not in out and "also" not in out
+    if world > 1:
+        assert out["s4_strong"]["speedup_event"] == 6.453 and out["streamed_s4"]["speedup"] == 6.486
+    # a line that would not fit is refused, never printed
+    full["config"]["workload"] = "w" * 5000
+    with pytest.raises(RuntimeError):
+        bench.contract_line(full)
+
+
+def test_side_file_holds_what_left_the_line(bench, tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    full = _full_object(bench, 1)
+    name = bench.write_side_file(full, [{"workload": "x", "ok": True}])
+    doc = json.loads((tmp_path / name).read_text())
+    assert doc["headline"]["roofline"]["method"].startswith("HIP events") and doc["also"][0]["workload"] == "x"
+    assert "launch_us_samples" in doc["headline"]["roofline"] and "timing" in doc["headline"]["config"]
 
 
 def test_wrong_world_size_is_refused():

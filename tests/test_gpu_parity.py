@@ -1259,19 +1259,38 @@ def test_integration_md_stub_runs_against_strassen_golden(golden, tmp_path):
 
 def test_bench_two_ranks_self_launched_on_one_gpu(tmp_path):
     """`python bench.py --gpus 2` with no launcher: bench.py starts its own ranks (torch.distributed.run children).
-    On the one-GPU box both ranks share the GPU and the control plane is gloo (TG_BENCH_BACKEND)."""
+    On the one-GPU box both ranks share the GPU and the control plane is gloo (TG_BENCH_BACKEND).  The contract line is
+    the LAST line of stdout, under 4 KB, and carries the sharded extras of an N>1 run: S=16 weak (value_s16) and strong,
+    config 4 strong with its single-GPU denominator, the resident stepper on the share, a short cpu_baseline."""
     import json, os, subprocess, sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(TG_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
-    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
-                          "--global-batch", "131072", "--no-also"], env=env, capture_output=True, text=True, timeout=600)
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                         env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
-    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
-    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 20 and out["samples"] == 9
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert lines[-1].startswith("{") and len(lines[-1]) < 4096
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 20 and out["samples"] == 9
     assert out["config"]["global_batch"] == 131072 and out["config"]["batch_per_gpu"] == 65536
     assert out["value"] > 1e9 and 0 < out["roofline"]["frac"] <= 1.0
+    assert out["value_s16"] > 1e7 and out["roofline_s16"]["kernel"].startswith("tg::s16_step_kernel") and out["ms_per_step_s16"] > 0
+    assert out["s16_strong"]["global_batch"] == 8192 and out["s16_strong"]["batch_per_gpu"] == 4096 and out["s16_strong"]["value"] > 1e7
+    s4 = out["s4_strong"]
+    assert s4["global_batch"] == 1 << 20 and s4["batch_per_gpu"] == 1 << 19 and s4["ideal"] == 2
+    assert s4["one_gpu_launch_us"] > 0 and s4["speedup_event"] > 0 and s4["speedup_wall"] > 0
+    st = out["streamed_s4"]
+    assert st["ok"] and st["share_us_per_step"] > 0 and st["one_gpu_us_per_step"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    # --scaling strong: config 4 is the headline and the weak figure moves to the side
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--scaling", "strong",
+                          "--global-batch", "131072", "--no-also", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 131072 and out["config"]["batch_per_gpu"] == 65536
 
 
 # ------------------------------------------------------------------ alternating sweep direction of tg_step_i8
@@ -1395,6 +1414,40 @@ def test_step_stream_beyond_the_resident_batch_runs_in_rounds_without_ready_word
         _, d = ops.step(ref, acts[k], out=ref)
         assert torch.equal(done[k], d)
     assert torch.equal(st, ref) and not bool(st.any()) and bool((prog == K).all())
+
+
+@pytest.mark.parametrize("S", [16, 25])
+def test_step_stream_capacity_and_ready_words_beyond_it(S):
+    """at S=16 / 25 tg_step_stream_layout accepts any B and the units run in rounds beyond the resident batch --
+    with ready words a producer that waits for the whole batch would never see the later rounds start.  The capacity is
+    now exported (from the occupancy of the stepper's kernel on this device); ready words beyond it are refused, the same
+    batch without them runs in rounds and equals K single steps."""
+    cap = ops.step_stream_capacity(S, DEV)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert cap == cus * {16: 32, 25: 16}[S]
+    assert ops.step_stream_capacity(4, DEV) >= 131072      # BASELINE config 4's share of 8 GPUs stays resident
+    B, K = cap + 37, 3
+    tok, tgt = ops.gen_demos(B, S, K, DEV, seed=9)
+    st = ops.alloc_states(B, S, DEV)
+    st.copy_(tgt)
+    acts = tok.permute(1, 0, 2).contiguous()
+    with pytest.raises(mat_mul_amd.TensorGameError, match="resident"):
+        ops.step_stream(st, acts, ready=torch.ones(K, dtype=torch.int32, device=DEV))
+    assert torch.equal(st, tgt)                          # refused before anything ran
+    prog = torch.zeros(B, dtype=torch.int32, device=DEV)
+    _, done = ops.step_stream(st, acts, progress=prog)
+    ref = ops.alloc_states(B, S, DEV)
+    ref.copy_(tgt)
+    for k in range(K):
+        _, d = ops.step(ref, acts[k], out=ref)
+        assert torch.equal(done[k], d)
+    assert torch.equal(st, ref) and not bool(st.any()) and bool((prog == K).all())
+    # at the capacity itself ready words are fine
+    st2 = ops.alloc_states(cap, S, DEV)
+    st2.copy_(tgt[:cap])
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.step_stream(st2, acts[:, :cap].contiguous(), ready=torch.ones(K, dtype=torch.int32, device=DEV), status=status)
+    assert int(status[0]) == 0 and not bool(st2.any())
 
 
 @pytest.mark.parametrize("S", [4, 16, 25])
