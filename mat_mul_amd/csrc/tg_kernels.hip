@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
       const int n = poll_now(kp);
       if (n) return n;
       const uint64_t now = __builtin_amdgcn_s_memrealtime();
-      if (t0 == 0) t0 = now | 1u;
+      if (t0 == 0) t0 = now;
       if (now - t0 >= a.wait_ticks) {
         if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return 0;
@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
       const int n = released(v, kp);
       if (n) return n;
       const uint64_t now = __builtin_amdgcn_s_memrealtime();
-      if (t0 == 0) t0 = now | 1u;
+      if (t0 == 0) t0 = now;
       if (now - t0 >= a.wait_ticks) {
         if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return 0;
@@ -1682,7 +1682,7 @@ __global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
       const int n = released(v, kp);
       if (n) return n;
       const uint64_t now = __builtin_amdgcn_s_memrealtime();
-      if (t0 == 0) t0 = now | 1u;
+      if (t0 == 0) t0 = now;
       if (now - t0 >= a.wait_ticks) {
         if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return 0;
