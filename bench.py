@@ -590,8 +590,8 @@ def streamed_time(b2, s2, k2, dev, seed=4, gid0=0, reps=5):
     if b2 <= ops.step_stream_capacity(s2, dev):
         n_units, gpw = ops.step_stream_layout(b2, s2, dev)
         ready = torch.ones(k2, dtype=torch.int32, device=dev)    # pre-set: the producer is never the bottleneck
-    else:  # beyond the resident batch: no ready words, the units (S=4: 16 games each, S=16/25: one game) run in rounds
-        n_units, gpw, ready = (-(-b2 // 16), 16, None) if s2 == 4 else (b2, 1, None)
+    else:  # beyond the resident batch: no ready words, the units (S=4: 64 games each, S=16/25: one game) run in rounds
+        n_units, gpw, ready = (-(-b2 // 64), 64, None) if s2 == 4 else (b2, 1, None)
     prog = torch.zeros(n_units, dtype=torch.int32, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     fn = lambda: ops.step_stream(st2, acts, done=dn, ready=ready, progress=prog, status=status)
@@ -891,8 +891,8 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
                          (25, 32768, 64)]:  # (the last two: BASELINE configs 4 and 5 whole on one GPU, units in rounds)
         sec, ok, gpw, how = streamed_time(b2, s2, k2, dev)
         # per step: tokens in, done out, and the state written through: the whole game once per block of steps
-        if s2 == 4:   # the state leaves once per block of D steps (D = 8 / 4 / 2 for 16 / 32 / more games per wavefront)
-            moved = b2 * (3 * s2 + 1) + b2 * s2 ** 3 / {16: 8, 32: 4}.get(gpw, 2)
+        if s2 == 4:   # the state leaves once per block of D steps (D = 8 for 16 or 64 games per wavefront, 4 for 32)
+            moved = b2 * (3 * s2 + 1) + b2 * s2 ** 3 / {16: 8, 32: 4, 64: 8}.get(gpw, 2)
         else:         # S=16 / S=25: whole games once per block of 8 steps
             moved = b2 * (3 * s2 + 1) + b2 * s2 ** 3 / 8
         also.append({"workload": f"STREAMED tg_step_stream_i8: S={s2} batch={b2}, K={k2} steps in ONE launch, actions "

@@ -115,7 +115,7 @@ int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* act
  * batch before releasing the next step additionally needs every unit resident at once: at S = 4
  * tg_step_stream_layout chooses the games per wavefront so that this holds and refuses batches beyond what the
  * device keeps resident (about 4.5e5 games on the 256 CUs of an MI355X; with ready == NULL tg_step_stream_i8 takes any B: units
- * of 16 games run in rounds, progress -- if given -- has (B + 15) / 16 words); S = 16 (one wavefront per game, the 4 KiB of
+ * of 64 games run in rounds, progress -- if given -- has (B + 63) / 64 words); S = 16 (one wavefront per game, the 4 KiB of
  * a game in registers) holds 32 games per CU = 8 192 on 256 CUs; S = 25 (one wavefront per game, the game's 15 625
  * bytes in registers) holds 16 games per CU = 4 096 on 256 CUs.  Beyond these (tg_step_stream_capacity) S = 16 / 25 run
  * their units in rounds too, with ready == NULL only: with ready words the call is refused (TG_ERR_UNSUPPORTED) -- a later

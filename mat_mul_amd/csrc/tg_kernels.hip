@@ -431,6 +431,43 @@ __device__ __forceinline__ void s4_step_biased(uint4& xb, uint32_t& l1, uint32_t
   l1 = __builtin_amdgcn_sad_u8(o.w, BIAS, __builtin_amdgcn_sad_u8(o.z, BIAS, __builtin_amdgcn_sad_u8(o.y, BIAS, __builtin_amdgcn_sad_u8(o.x, BIAS, 0u))));
 }
 
+// Reductions over the four lanes of a team (a DPP quad): two VALU instructions with the exchange folded in (v_add_u32_dpp /
+// v_or_b32_dpp), every lane ends with the team's value.  team_any<4> does the same through a ballot: v_cmp + four v_and +
+// two 64-bit compares per use -- a third of the resident stepper's step before round 4.
+__device__ __forceinline__ uint32_t quad_sum(uint32_t x) {
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+  return x;
+}
+__device__ __forceinline__ uint32_t quad_or(uint32_t x) {
+  x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0xB1, 0xf, 0xf, false));
+  x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x4E, 0xf, 0xf, false));
+  return x;
+}
+
+// s4_step_biased for a caller that has tested the tokens of a whole BLOCK of steps at once (`wide`: some token byte of the
+// block exceeds 3, team-uniform): the per-step or / and / compare of the twelve bytes leaves the step.
+__device__ __forceinline__ void s4_step_biased_blk(uint4& xb, uint32_t& l1, uint32_t du, uint32_t dv, uint32_t dw, int q, int shift,
+                                                   int digits_limit, bool wide, int& ovf) {
+  constexpr uint32_t BIAS = 0x80808080u;
+  const uint32_t nui = static_cast<uint32_t>(shift) - (__builtin_amdgcn_alignbyte(du, du, static_cast<uint32_t>(q)) & 255u);
+  const uint32_t W = dw - static_cast<uint32_t>(shift) * 0x01010101u;
+  const uint32_t G = mul_lo_mad(nui, W);
+  uint32_t vj[4];
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(vj[0]) : "v"(dv), "s"(shift));
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(vj[1]) : "v"(dv), "s"(shift));
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(vj[2]) : "v"(dv), "s"(shift));
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(vj[3]) : "v"(dv), "s"(shift));
+  uint4 o{xb.x + vj[0] * G, xb.y + vj[1] * G, xb.z + vj[2] * G, xb.w + vj[3] * G};
+  if (__builtin_expect(wide || static_cast<int>(l1) > digits_limit, 0)) {
+    uint32_t nz = 0;
+    const uint4 r = s4_step_slice(uint4{xb.x ^ BIAS, xb.y ^ BIAS, xb.z ^ BIAS, xb.w ^ BIAS}, du, dv, dw, q, shift, nz, ovf);
+    o = uint4{r.x ^ BIAS, r.y ^ BIAS, r.z ^ BIAS, r.w ^ BIAS};
+  }
+  xb = o;
+  l1 = __builtin_amdgcn_sad_u8(o.w, BIAS, __builtin_amdgcn_sad_u8(o.z, BIAS, __builtin_amdgcn_sad_u8(o.y, BIAS, __builtin_amdgcn_sad_u8(o.x, BIAS, 0u))));
+}
+
 // The game's 12 token bytes as three dwords (u | v | w) in every lane of its 4-lane team from ONE dword load per lane:
 // lane q loads dword min(q, 2) and the team exchanges them by DPP quad broadcasts (three v_mov_b32_dpp).  A
 // global_load_dwordx3 per lane asks the memory pipeline for 48 bytes per game where 12 are distinct; with the token
@@ -981,9 +1018,11 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
   }
   // the slices stay biased for all K steps, each with its L1 norm (s4_step_biased); un-biased when they are stored
   uint32_t l1s[NG];
+  int ovfs[NG];  // bits beyond the low byte: an entry left int8 (general form only); written out once per block
 #pragma unroll
   for (int n = 0; n < NG; ++n) {
     uint32_t xb[4];
+    ovfs[n] = 0;
     l1s[n] = s4_digits_pre(pk[n], xb);
     pk[n] = uint4{xb[0], xb[1], xb[2], xb[3]};
   }
@@ -1061,6 +1100,16 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
   int kb = 0;                                         // first step of the block (uniform)
   int nb = a.ready ? wait_released(0) : (a.K < D ? a.K : D);  // its steps: released, not yet requested
   if (nb == 0) return;
+  // STAGGER (round 4).  All resident wavefronts start together and do identical work, so they stay in lockstep: every
+  // wavefront of a SIMD waits for its block's tokens at the same time and then all compute at once.  The FIRST block is cut
+  // to 1 .. D steps by the workgroup's residency slot on its CU (consecutive workgroups go round the 8 XCDs, then round an
+  // XCD's 32 CUs: blockIdx / 256 counts the slots), which spreads the wavefronts of a SIMD over the period: 0.776 -> 0.754 us
+  // per step at 131 072 games with ready words, nothing without (same run, A/B).  What bounds this kernel at full occupancy
+  // is the number of its small memory operations (the lane kernel below has the ablation), not the phase of its wavefronts.
+  if constexpr (D > 1) {
+    const int first = 1 + static_cast<int>((blockIdx.x >> 8) & (D - 1));
+    nb = nb < first ? nb : first;
+  }
   bool fresh = true;  // nothing stored since the last publish (the first block; after the serial order below)
   for (;;) {
     const bool with_poll = a.ready && kb + nb < a.K;  // uniform
@@ -1074,22 +1123,45 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     arrived();
+    // (round 4) per BLOCK: does any token byte of the team's steps exceed 3?  (lane q holds dword min(q, 2) of every step's
+    // twelve bytes; steps beyond nb repeat valid ones, at worst they send a block through the general form needlessly)
+    bool wide[NG];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      if (d >= nb) break;  // uniform
+    for (int n = 0; n < NG; ++n) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) w |= tk[d][n];
+      wide[n] = quad_or(w & 0xFCFCFCFCu) != 0;
+    }
+    // one step of every game of the wavefront: done[k] from the team's summed L1 norms (two DPP adds); the overflow flags
+    // are only ever raised inside the general form and leave once per block
+    auto one_step = [&](int d) {
       const int k = kb + d;
 #pragma unroll
       for (int n = 0; n < NG; ++n) {
         uint32_t du, dv, dw;
         s4_team_token_bcast(tk[d][n], du, dv, dw);
-        int ovf = 0;
-        s4_step_biased(pk[n], l1s[n], du, dv, dw, q, a.shift, dig_limit, ovf);
-        const bool any_nz = team_any<4>(l1s[n] != 0);
-        const bool any_ovf = team_any<4>((ovf & ~255) != 0);
-        if (live[n] && q == 0) {  // write-through (sc1) stores: visible to other agents once this wavefront's vmcnt drains
-          __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(any_nz ? 0 : 1), drs,
+        s4_step_biased_blk(pk[n], l1s[n], du, dv, dw, q, a.shift, dig_limit, wide[n], ovfs[n]);
+        const uint32_t team_l1 = quad_sum(l1s[n]);
+        if (live[n] && q == 0)  // write-through (sc1) stores: visible to other agents once this wavefront's vmcnt drains
+          __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(team_l1 == 0 ? 1 : 0), drs,
                                                static_cast<int>(static_cast<int64_t>(k) * a.B + g[n]), 0, 16);
-          if (a.overflow && any_ovf) a.overflow[g[n]] = 1;
+        // one game at a time: left alone hipcc interleaves the NG games of a step (nothing convergent separates them any
+        // more) and NG = 4 / 8 need 103 / 196 VGPRs instead of 72 / 128 -- half the resident batch
+        if constexpr (NG > 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (d >= nb) break;  // uniform
+      one_step(d);
+    }
+    if (a.overflow) {
+#pragma unroll
+      for (int n = 0; n < NG; ++n) {
+        if (__builtin_expect(quad_or(static_cast<uint32_t>(ovfs[n]) & ~255u) != 0, 0)) {
+          if (live[n] && q == 0) a.overflow[g[n]] = 1;
+          ovfs[n] = 0;  // (sticky in memory: raised once is enough)
         }
       }
     }
@@ -1120,6 +1192,246 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
   if (a.progress) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's last stores have left
     if (lane == 0) __hip_atomic_store(a.progress + unit, static_cast<uint32_t>(a.K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// =============================================================================================
+// tg_step_stream_i8, S = 4, ONE GAME PER LANE (round 4).  Ablation of s4_stream_kernel<1> at BASELINE config 4's share
+// (131 072 games resident, tools/stream_ablate.sh): without its arithmetic 0.77 of 0.84 us per step, without the done
+// stores 0.57, without any store 0.49 -- the stepper is bound by the NUMBER of small memory operations (a 16-lane byte
+// store and a 192-byte token load per 16 games and step, write-through), not by its instructions.  Here a lane owns a
+// whole game (sixteen biased dwords X[i][j], the digits are the l index) and a wavefront 64 games:
+//   tokens  one global_load_dwordx3 per lane and step: 768 contiguous bytes per wavefront (were 4 x 192);
+//   done    one 64-byte row per wavefront and step (were 4 x 16 bytes);
+//   state   once per block, transposed through 4 KiB of LDS per wavefront so that every store instruction writes 1 KiB
+//           in a row (lane-strided 16-byte pieces would be partial lines);
+//   VALU    per step 4 + 4 byte extractions, 4 products G_i = -u_i W, 16 multiply-adds X[i][j] += v_j G_i, 16 v_sad_u8:
+//           ~48 instructions for 64 games (the four-lanes-per-game form: ~27 for 16).
+// A step some lane's digit form does not cover (tokens > 3, entries near the int8 range, other shifts) is taken by the
+// WHOLE wavefront through the general form on an LDS image of its games (s4_step_slice per slice, rolled): exact, rare.
+// Protocol (ready / progress / status, blocks of up to D released steps, counted waits) as s4_stream_kernel.
+// =============================================================================================
+__global__ __launch_bounds__(kBlock) void s4_stream_kernel_lanes(StreamArgs a) {
+  typedef unsigned int tg_u32x3 __attribute__((ext_vector_type(3)));
+  typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int D = 8, NW = kBlock / 64;
+  constexpr uint32_t BIAS = 0x80808080u;
+  constexpr int kDropped = static_cast<int>(0x80000000u);  // a buffer offset beyond every range: the store is dropped
+  __shared__ __attribute__((aligned(16))) uint32_t img[NW][64 * 16];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * NW + wave;
+  const int64_t g0 = unit * 64;
+  if (g0 >= a.B) return;
+  // (range-checked buffers: a dead lane's store goes to kDropped instead of being branched around, so the number of
+  // memory operations a block issues is exact -- the counted waits below depend on it)
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.state, 0, static_cast<int>(a.B * a.stride), 0x00027000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(a.done, 0, static_cast<int>(static_cast<int64_t>(a.K) * a.B), 0x00027000);
+  const bool live = g0 + lane < a.B;
+  const int64_t g = live ? g0 + lane : a.B - 1;  // dead lanes shadow the last game
+  uint32_t* const row = &img[wave][lane * 16];
+  uint32_t x[16];
+  {
+    const int8_t* src = a.state + g * a.stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src + 16 * i);
+      x[4 * i] = v.x ^ BIAS, x[4 * i + 1] = v.y ^ BIAS, x[4 * i + 2] = v.z ^ BIAS, x[4 * i + 3] = v.w ^ BIAS;
+    }
+  }
+  auto norm = [&]() {
+    uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+      s0 = __builtin_amdgcn_sad_u8(x[e], BIAS, s0);
+      s1 = __builtin_amdgcn_sad_u8(x[e + 1], BIAS, s1);
+    }
+    return s0 + s1;
+  };
+  uint32_t l1 = norm();
+  int ovf = 0;
+  const int dig_limit = s4_digits_limit(a.shift);
+  const uint32_t shrep = static_cast<uint32_t>(a.shift) * 0x01010101u;
+  // TWO sets of token registers: while the block in tkA is worked on, the next block's tokens travel into tkB (a wavefront
+  // alone on its SIMD -- 65 536 games -- otherwise waits a memory round trip per block with nothing to issue)
+  tg_u32x3 tkA[D], tkB[D];
+  uint32_t pollv = 0u;
+  const uint32_t toff = static_cast<uint32_t>(g) * 12u;
+  // poll of ready[kp + lane], lane < D (with_poll), then the tokens of steps kb .. kb + D - 1 (steps beyond K - 1 repeat the
+  // last one; what lies beyond the released steps is loaded and at most OR-ed into the block's `wide` test)
+  auto request = [&](tg_u32x3 (&tk)[D], int kb, int kp, bool with_poll) {
+    if (with_poll) {
+      const uint32_t* rp = a.ready + kp;
+      const uint32_t poff = (lane < D && kp + lane < a.K) ? 4u * lane : 0u;
+      asm volatile("global_load_dword %0, %1, %2 sc1" : "=&v"(pollv) : "v"(poff), "s"(rp) : "memory");
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int kd = kb + d < a.K ? kb + d : a.K - 1;
+      const int8_t* blk = a.actions + static_cast<int64_t>(kd) * a.B * 12;
+      asm volatile("global_load_dwordx3 %0, %1, %2 sc1" : "=&v"(tk[d]) : "v"(toff), "s"(blk) : "memory");
+    }
+  };
+  auto arrived = [&](tg_u32x3 (&tk)[D]) {  // behind the wait that covers them: from here on the registers hold the loaded values
+#pragma unroll
+    for (int d = 0; d < D; ++d) asm volatile("" : "+v"(tk[d]));
+    asm volatile("" : "+v"(pollv));
+  };
+  auto released = [&](uint32_t v, int kp) {
+    const unsigned long long m = __ballot(lane < D && kp + lane < a.K && v != 0);
+    return static_cast<int>(__builtin_ctzll(~m));  // uniform, <= D
+  };
+  auto wait_released = [&](int kp) {  // bounded in TIME (a.wait_ticks); 0 = gave up
+    uint64_t t0 = 0;
+    for (;;) {
+      const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const int n = released(v, kp);
+      if (n) return n;
+      const uint64_t now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now;
+      if (now - t0 >= a.wait_ticks) {
+        if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  };
+  auto publish = [&](int k) {
+    if (lane == 0) __hip_atomic_store(a.progress + unit, static_cast<uint32_t>(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // how many steps the block behind step kn - 1 has, from the poll that travelled with the block before it
+  auto next_size = [&](int kn) {
+    if (kn >= a.K) return 0;
+    return a.ready ? released(pollv, kn) : (a.K - kn < D ? a.K - kn : D);
+  };
+  // the digit form of one step for the lane's game
+  auto fast_step = [&](const tg_u32x3& t) {
+    const uint32_t W = t.z - shrep;
+    uint32_t G[4], vj[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) G[i] = mul_lo_mad(static_cast<uint32_t>(a.shift) - ((t.x >> (8 * i)) & 255u), W);
+    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(vj[0]) : "v"(t.y), "s"(a.shift));
+    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(vj[1]) : "v"(t.y), "s"(a.shift));
+    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(vj[2]) : "v"(t.y), "s"(a.shift));
+    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(vj[3]) : "v"(t.y), "s"(a.shift));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[4 * i + j] += vj[j] * G[i];
+    l1 = norm();
+  };
+  // the general form of one step for every game of the wavefront, on an LDS image (each lane touches its own row only)
+  auto general_step = [&](const tg_u32x3& t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(row + 4 * i) = uint4{x[4 * i] ^ BIAS, x[4 * i + 1] ^ BIAS, x[4 * i + 2] ^ BIAS, x[4 * i + 3] ^ BIAS};
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      uint32_t nz = 0;
+      const uint4 r = s4_step_slice(*reinterpret_cast<const uint4*>(row + 4 * i), t.x, t.y, t.z, i, a.shift, nz, ovf);
+      *reinterpret_cast<uint4*>(row + 4 * i) = r;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * i);
+      x[4 * i] = v.x ^ BIAS, x[4 * i + 1] = v.y ^ BIAS, x[4 * i + 2] = v.z ^ BIAS, x[4 * i + 3] = v.w ^ BIAS;
+    }
+    l1 = norm();
+  };
+#pragma unroll
+  for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(x[e]));  // the state is in its registers before the first asm load
+  int kb = 0;                                                    // first step of the block in tkA (uniform)
+  int nb = a.ready ? wait_released(0) : (a.K < D ? a.K : D);     // its steps
+  if (nb == 0) return;
+  int nb_next = 0;       // steps of the block behind it, as far as they were SEEN released
+  int pub = 0;           // > 0: steps [.., pub) are stored but not yet published
+  bool have = false;     // tkA holds this block's tokens
+  for (;;) {
+    if (!have) {  // the serial order (first block; after a spin): request, drain everything, publish what was pending
+      request(tkA, kb, kb + nb, a.ready && kb + nb < a.K);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      arrived(tkA);
+      if (a.progress && pub) publish(pub);
+      pub = 0;
+      nb_next = next_size(kb + nb);
+    }
+    // ---- the next block's tokens set off before this block is worked on (only steps SEEN released are ever requested)
+    const int kn = kb + nb;
+    const bool pf = nb_next > 0;                              // uniform
+    const bool poll2 = a.ready && kn + nb_next < a.K;         // uniform
+    if (pf) request(tkB, kn, kn + nb_next, poll2);
+    // ---- this block: does any token byte of the lane's steps exceed 3?
+    uint32_t wq = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) wq |= tkA[d].x | tkA[d].y | tkA[d].z;
+    const bool wide = (wq & 0xFCFCFCFCu) != 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (d >= nb) break;  // uniform
+      if (__builtin_expect(__ballot(wide || static_cast<int>(l1) > dig_limit) != 0, 0)) general_step(tkA[d]);
+      else fast_step(tkA[d]);
+      // write-through (sc1) stores: visible to other agents once this wavefront's vmcnt drains
+      __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(l1 == 0 ? 1 : 0), drs,
+                                           live ? static_cast<int>(static_cast<int64_t>(kb + d) * a.B + g) : kDropped, 0, 16);
+    }
+    if (a.overflow && __builtin_expect(__ballot((ovf & ~255) != 0) != 0, 0)) {  // (one more store than counted: the waits then
+      if (live && (ovf & ~255)) a.overflow[g] = 1;                               // cover one operation more than they need to)
+      ovf = 0;  // sticky in memory: raised once is enough
+    }
+    // the state leaves once per block, transposed through LDS: chunk c = lane + 64 r is 16-byte piece c & 3 of game c >> 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(row + 4 * i) = uint4{x[4 * i] ^ BIAS, x[4 * i + 1] ^ BIAS, x[4 * i + 2] ^ BIAS, x[4 * i + 3] ^ BIAS};
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = lane + 64 * r;
+      const uint4 v = *reinterpret_cast<const uint4*>(&img[wave][4 * c]);
+      const int64_t gg = g0 + (c >> 2);
+      __builtin_amdgcn_raw_buffer_store_b128(tg_u32x4{v.x, v.y, v.z, v.w}, srs,
+                                             gg < a.B ? static_cast<int>(gg * a.stride) + 16 * (c & 3) : kDropped, 0, 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- in flight now, oldest first: [stores of the block before] [tkB's L = D (+1) loads] [this block's nb + 4 stores]
+    const bool whole = nb == D;  // (a partial block -- the last one, or a producer releasing step by step -- drains instead)
+    if (a.progress && pub) {  // the block before is visible once everything older than tkB's loads has left
+      if (!whole || !pf) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (poll2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + 1 + D + 4) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + D + 4) : "memory");
+      publish(pub);
+      pub = 0;
+      if (pf) {  // tkB: older than this block's D + 4 stores and that progress store
+        if (whole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + 4 + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else if (pf) {
+      if (whole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + 4) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    pub = kn;
+    kb = kn;
+    if (kb >= a.K) break;
+    if (pf) {
+      arrived(tkB);
+#pragma unroll
+      for (int d = 0; d < D; ++d) tkA[d] = tkB[d];
+      nb = nb_next;
+      nb_next = next_size(kb + nb);
+      have = true;
+    } else {  // nothing seen released beyond this block: drain, publish, spin
+      if (a.progress) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish(pub);
+      }
+      pub = 0;
+      nb = wait_released(kb);
+      if (nb == 0) return;
+      have = false;
+    }
+  }
+  if (a.progress) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's last stores have left
+    publish(a.K);
   }
 }
 
@@ -2500,18 +2812,48 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
 constexpr uint32_t kStreamWaitTicks = 100000000u;  // 1.0 s of s_memrealtime (100 MHz)
 
 // Units of each streamed-stepper variant this device keeps resident at once (from the occupancy of ITS kernel on THIS device).
-// S = 4: NG games x 16 per wavefront (NG = 1, 2 run 8 workgroups per CU, NG = 4 seven, NG = 8 three on gfx950).
+// S = 4: NG games x 16 per wavefront (NG = 1, 2 run 8 workgroups per CU, NG = 4 / 8 fewer), or 64 games per wavefront in the
+// one-game-per-lane kernel (kStreamLanes; four workgroups per CU at 122 VGPRs).
+constexpr int kStreamLanes = 0;
 static int64_t stream_units_resident(int S, int ng) {
-  static OccupancySlots occ1, occ2, occ4, occ8, occ16, occ25;
+  static OccupancySlots occ1, occ2, occ4, occ8, occ16, occ25, occl;
   const int64_t cus = device_cu_count();
   if (S == 16) return cus * 4 * resident_per_cu(tg::s16_stream_kernel, 0, occ16);
   if (S == 25) return cus * 4 * resident_per_cu(tg::s25_stream_kernel, 0, occ25);
   switch (ng) {
+    case kStreamLanes: return cus * 4 * resident_per_cu(tg::s4_stream_kernel_lanes, 0, occl);
     case 1: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<1>, 0, occ1);
     case 2: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<2>, 0, occ2);
     case 4: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<4>, 0, occ4);
     default: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<8>, 0, occ8);
   }
+}
+
+// S = 4: which kernel takes a resident batch of B games.  From kLanesFrom games on the one-game-per-lane kernel (measured,
+// four-lanes-per-game / one-game-per-lane, us per step with ready words and progress: 32 768 games 0.34 / 0.38, 49 152
+// 0.38 / 0.39, 65 536 0.42 / 0.40, 98 304 0.58 / 0.47, 131 072 0.82 / 0.48, 262 144 1.97 / 0.90 before its token
+// prefetch); below that, and beyond what it holds, the smallest NG whose units all fit.  Returns NG (kStreamLanes for
+// the lane kernel) or -1 when no variant keeps B games resident; *most = the largest batch any variant holds.
+constexpr int64_t kLanesFrom = 57344;
+static int s4_stream_variant(int64_t B, int64_t* units, int* games_per_unit, int64_t* most) {
+  int64_t best = 0;
+  const int64_t lane_cap = stream_units_resident(4, kStreamLanes);
+  best = lane_cap * 64;
+  const bool lanes_ok = !TG_SWITCH("TG_STREAM_NO_LANES") && (B + 63) / 64 <= lane_cap;
+  if (lanes_ok && (B >= kLanesFrom || TG_SWITCH("TG_STREAM_LANES"))) {
+    *units = (B + 63) / 64, *games_per_unit = 64;
+    return kStreamLanes;
+  }
+  for (int ng = 1; ng <= 8; ng *= 2) {
+    const int64_t u = (B + 16 * ng - 1) / (16 * ng), cap = stream_units_resident(4, ng);
+    if (u <= cap) {
+      *units = u, *games_per_unit = 16 * ng;
+      return ng;
+    }
+    best = cap * 16 * ng > best ? cap * 16 * ng : best;
+  }
+  if (most) *most = best;
+  return -1;
 }
 
 /* the largest batch tg_step_stream_i8 takes WITH ready words: every unit resident at once on the current device */
@@ -2521,6 +2863,7 @@ int tg_step_stream_capacity(int S, int64_t* games) {
   if (!games) return fail(TG_ERR_INVALID, "tg_step_stream_capacity: null pointer");
   int64_t most = 0;
   if (S == 4) {
+    most = stream_units_resident(4, kStreamLanes) * 64;
     for (int ng = 1; ng <= 8; ng *= 2) {
       const int64_t c = stream_units_resident(4, ng) * 16 * ng;
       most = c > most ? c : most;
@@ -2542,20 +2885,15 @@ int tg_step_stream_layout(int64_t B, int S, int64_t* n_units, int* games_per_uni
     if (games_per_unit) *games_per_unit = 1;
     return TG_OK;
   }
-  // S = 4: every wavefront must be resident at once when the producer waits for the whole batch; the smallest NG whose
-  // units all fit is chosen.
-  int64_t most = 0;
-  for (int ng = 1; ng <= 8; ng *= 2) {
-    const int64_t units = (B + 16 * ng - 1) / (16 * ng), cap = stream_units_resident(4, ng);
-    if (units <= cap) {
-      if (n_units) *n_units = units;
-      if (games_per_unit) *games_per_unit = 16 * ng;
-      return TG_OK;
-    }
-    most = cap * 16 * ng > most ? cap * 16 * ng : most;
-  }
-  return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: B=%lld exceeds the %lld games this device keeps resident at once",
-              (long long)B, (long long)most);
+  // S = 4: every wavefront must be resident at once when the producer waits for the whole batch
+  int64_t units = 0, most = 0;
+  int gpu_ = 0;
+  if (s4_stream_variant(B, &units, &gpu_, &most) < 0)
+    return fail(TG_ERR_UNSUPPORTED, "tg_step_stream_layout: B=%lld exceeds the %lld games this device keeps resident at once",
+                (long long)B, (long long)most);
+  if (n_units) *n_units = units;
+  if (games_per_unit) *games_per_unit = gpu_;
+  return TG_OK;
 }
 
 int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8_t* overflow, const uint32_t* ready,
@@ -2566,14 +2904,21 @@ int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8
   if (K < 1 || K > (1 << 24)) return fail(TG_ERR_INVALID, "%s: K=%d outside [1,2^24]", fn, K);
   if (B == 0) return TG_OK;
   if (!state || !actions || !done) return fail(TG_ERR_INVALID, "%s: null pointer", fn);
-  int64_t units = 0;
-  int gpu_ = 0;
-  if (int rc = tg_step_stream_layout(B, S, &units, &gpu_)) {
-    // S = 4 beyond what the device keeps resident: without ready words no producer can be waiting for the whole batch, so
-    // the units (16 games each) simply run in rounds, every wavefront taking its games through all K steps
-    if (!(rc == TG_ERR_UNSUPPORTED && S == 4 && !ready && B > 0)) return rc;
-    units = (B + 15) / 16;
-    gpu_ = 16;
+  if (S != 4 && S != 16 && S != 25)
+    return fail(TG_ERR_UNSUPPORTED, "%s: S=%d (the streamed stepper is built for S=4, S=16 and S=25)", fn, S);
+  int64_t units = B;  // S = 16 / 25: one wavefront per game
+  int gpu_ = 1, variant = 1;
+  if (S == 4) {
+    variant = s4_stream_variant(B, &units, &gpu_, nullptr);
+    if (variant < 0) {
+      // beyond what the device keeps resident: without ready words no producer can be waiting for the whole batch, so the
+      // units (64 games each, the one-game-per-lane kernel) simply run in rounds, every wavefront taking its games
+      // through all K steps
+      if (ready) return tg_step_stream_layout(B, S, nullptr, nullptr);  // (fails with the message that names the capacity)
+      variant = TG_SWITCH("TG_STREAM_NO_LANES") ? 1 : kStreamLanes;
+      gpu_ = variant == kStreamLanes ? 64 : 16;
+      units = (B + gpu_ - 1) / gpu_;
+    }
   }
   // S = 16 / 25 beyond the resident batch run in rounds as well -- and with ready words a producer that releases step k+1
   // only once EVERY unit has published k would never see the later rounds start (each would wait out its whole bound and
@@ -2602,7 +2947,8 @@ int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8
     hipLaunchKernelGGL(tg::s25_stream_kernel, dim3(grid), dim3(tg::kBlock), 0, st, a);
     return check_launch(fn);
   }
-  switch (gpu_ / 16) {
+  switch (variant) {
+    case kStreamLanes: hipLaunchKernelGGL(tg::s4_stream_kernel_lanes, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
     case 1: hipLaunchKernelGGL(tg::s4_stream_kernel<1>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
     case 2: hipLaunchKernelGGL(tg::s4_stream_kernel<2>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
     case 4: hipLaunchKernelGGL(tg::s4_stream_kernel<4>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;

@@ -243,7 +243,7 @@ def step_stream(state, actions, done=None, overflow=None, ready=None, progress=N
         except TensorGameError:
             if ready is not None or S != 4:
                 raise
-            n_units = -(-B // 16)  # beyond the resident batch, without ready words: units of 16 games in rounds
+            n_units = -(-B // 64)  # beyond the resident batch, without ready words: units of 64 games in rounds
         if progress.numel() < n_units:
             raise TensorGameError("step_stream", -1, "progress needs one word per unit (ops.step_stream_layout)")
     with torch.cuda.device(dev):

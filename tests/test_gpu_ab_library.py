@@ -187,6 +187,90 @@ def test_write_stream_variants_stay_exact(env_name, tmp_path):
     _run(STREAM_SCRIPT, tmp_path, "STREAM_OK", {env_name: "1"})
 
 
+LANES_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from mat_mul_amd import ops, _lib
+from oracle import tensor_game as O
+assert _lib.AB_VARIANT
+DEV = "cuda:0"
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+host = lambda t: t.detach().cpu().numpy()
+S = 4
+for B, K in [(1, 3), (63, 5), (64, 9), (65, 17), (1000, 14), (4099, 25)]:
+    rng = np.random.default_rng(B * 31 + K)
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(K, B, 3 * S)).astype(np.int8)
+    st[::5] = O.action_to_tensor(ac[0, ::5]).astype(np.int8)
+    if B > 3:
+        st[3] = 127
+        ac[1, 3] = 0                                                       # overflows at step 1
+        ac[2, 2] = rng.integers(-3, 6, size=3 * S)                         # wide factors: the general form
+        ac[K - 1, 1::4] = rng.integers(0, 3, size=ac[K - 1, 1::4].shape)
+        ac[:, B - 1] = rng.integers(-128, 128, size=(K, 3 * S))            # full-range tokens in the last (ragged) unit
+    for shift in (1, 2, -1):
+        want_done, want_ovf, cur = np.zeros((K, B), np.uint8), np.zeros(B, np.uint8), st.copy()
+        for k in range(K):
+            cur, d, o = O.step_i8(cur, ac[k], shift=shift)
+            want_done[k] = d
+            want_ovf |= o
+        want_lanes = "TG_STREAM_NO_LANES" not in __import__("os").environ
+        n_units, gpu = ops.step_stream_layout(B, S, DEV)
+        assert (gpu == 64) == want_lanes and n_units == -(-B // gpu)
+        for ready in (None, torch.ones(K, dtype=torch.int32, device=DEV)):
+            t = ops.alloc_states(B, S, DEV); t.copy_(dev(st))
+            ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+            prog = torch.zeros(n_units, dtype=torch.int32, device=DEV)
+            status = torch.zeros(1, dtype=torch.int32, device=DEV)
+            out, done = ops.step_stream(t, dev(ac), overflow=ovf, ready=ready, progress=prog, status=status, shift=shift)
+            torch.cuda.synchronize()
+            assert np.array_equal(host(t), cur) and np.array_equal(host(done), want_done) and np.array_equal(host(ovf), want_ovf), (B, K, shift)
+            assert bool((prog == K).all()) and int(status[0]) == 0
+# released step by step from a second stream (blocks of one: the serial order), then in bursts
+B, K = 300, 21
+rng = np.random.default_rng(5)
+st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(K, B, 3 * S)).astype(np.int8)
+want_done, cur = np.zeros((K, B), np.uint8), st.copy()
+for k in range(K):
+    cur, want_done[k], _ = O.step_i8(cur, ac[k])
+for bursts in ((1,) * K, (1, 4, 2, 9, 1, 3, 8, 8)):
+    t = ops.alloc_states(B, S, DEV); t.copy_(dev(st))
+    ready = torch.zeros(K, dtype=torch.int32, device=DEV)
+    ready[:3] = 1; ready[4:6] = 1; ready[K - 1] = 1
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    prog = torch.zeros(ops.step_stream_layout(B, S, DEV)[0], dtype=torch.int32, device=DEV)
+    done = torch.zeros((K, B), dtype=torch.uint8, device=DEV)
+    acd = dev(ac)
+    torch.cuda.synchronize()
+    side, prod = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+    with torch.cuda.stream(side):
+        ops.step_stream(t, acd, done=done, ready=ready, progress=prog, status=status)
+    with torch.cuda.stream(prod):
+        k = 3
+        for b in bursts:
+            ready[k:min(K, k + b)].fill_(1)
+            prod.synchronize()
+            k += b
+            if k >= K:
+                break
+    side.synchronize()
+    assert int(status[0]) == 0
+    assert np.array_equal(host(t), cur) and np.array_equal(host(done), want_done) and bool((prog == K).all())
+print("LANES_OK")
+'''
+
+
+@pytest.mark.parametrize("env_name", ["TG_STREAM_LANES", "TG_STREAM_NO_LANES"])
+def test_stream_lane_kernel_forced_at_small_batches(env_name, tmp_path):
+    """Round 4: s4_stream_kernel_lanes (one game per lane, tokens double-buffered, counted waits over an exact number of
+    stores) serves tg_step_stream_i8 from 57 344 games on; TG_STREAM_LANES forces it at every batch -- single games, ragged
+    units, shifts 1 / 2 / -1 (the last two leave the digit form: the whole wavefront takes the general form on its LDS
+    image), overflow, full-range tokens, ready words pre-set, released one by one and in bursts.  TG_STREAM_NO_LANES: the
+    four-lanes-per-game kernels on the same cases."""
+    _run(LANES_SCRIPT, tmp_path, "LANES_OK", {env_name: "1"})
+
+
 def test_product_library_has_no_switches():
     """The product library reads no environment variable and does not export the A/B-only entry."""
     import ctypes as C

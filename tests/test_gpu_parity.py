@@ -1396,7 +1396,7 @@ def test_step_stream_waits_for_ready_words_and_times_out():
 
 def test_step_stream_beyond_the_resident_batch_runs_in_rounds_without_ready_words():
     """S=4 with more games than the device keeps resident: refused with ready words (a producer waiting for the whole batch
-    would stall), accepted without -- units of 16 games run in rounds; BASELINE config 4 whole on one GPU."""
+    would stall), accepted without -- units of 64 games run in rounds; BASELINE config 4 whole on one GPU."""
     B, K = 1 << 20, 3
     with pytest.raises(mat_mul_amd.TensorGameError, match="resident"):
         ops.step_stream_layout(B, 4, DEV)
@@ -1406,7 +1406,7 @@ def test_step_stream_beyond_the_resident_batch_runs_in_rounds_without_ready_word
     acts = tok.permute(1, 0, 2).contiguous()
     with pytest.raises(mat_mul_amd.TensorGameError, match="resident"):
         ops.step_stream(st, acts, ready=torch.ones(K, dtype=torch.int32, device=DEV))
-    prog = torch.zeros(B // 16, dtype=torch.int32, device=DEV)
+    prog = torch.zeros(B // 64, dtype=torch.int32, device=DEV)          # in rounds: units of 64 games
     _, done = ops.step_stream(st, acts, progress=prog)
     ref = ops.alloc_states(B, 4, DEV)
     ref.copy_(tgt)
@@ -1561,27 +1561,31 @@ def test_step_stream_refuses_what_it_does_not_implement():
 
 
 def test_step_stream_layout_never_exceeds_what_the_device_keeps_resident():
-    """the S=4 layout must come from the occupancy of the variant it selects (NG = 4 holds 7 wavefronts per
-    SIMD, NG = 8 three -- not the 8 the first version assumed): every accepted batch has all its units resident at
-    once, larger batches are refused instead of stalling a producer that waits for the whole batch."""
+    """the S=4 layout must come from the occupancy of the variant it selects: every accepted batch has all its
+    units resident at once, larger batches are refused instead of stalling a producer that waits for the whole batch.
+    Round 4: from 57 344 games on the one-game-per-lane kernel (64 games per unit) takes every batch it holds."""
     cus = torch.cuda.get_device_properties(0).multi_processor_count
+    cap = ops.step_stream_capacity(4, DEV)
     seen = set()
-    for B in [1, 15, 16, 17, 4096, 65536, 131072, 200000, 262144, 300000, 400000, 458752, 500000, 1 << 19, 1 << 20]:
+    for B in [1, 15, 16, 17, 4096, 57343, 57344, 65536, 131072, 200000, 262144, 300000, 400000, 458752, 500000, 1 << 19, 1 << 20]:
         try:
             units, gpu = ops.step_stream_layout(B, 4, DEV)
         except mat_mul_amd.TensorGameError as e:
-            assert "resident" in str(e) and B > 131072
+            assert "resident" in str(e) and B > 131072 and B > cap
             continue
+        assert B <= cap
         assert gpu in (16, 32, 64, 128) and units == -(-B // gpu)
         assert units <= cus * 32                                          # never more than 8 wavefronts per SIMD
-        # (the caps of the variants with several games per lane follow their register use -- the library asks the
-        # runtime for the occupancy of the kernel it selects; round 2's NG = 8 held 3 wavefronts per SIMD, round 3's 4)
         if gpu == 128:
             assert units <= cus * 24
+        if 57344 <= B <= 262144:
+            assert gpu == 64 and units <= cus * 16                        # the lane kernel: four wavefronts per SIMD
+        if B < 57344:
+            assert gpu == 16
         seen.add(gpu)
-    assert {16, 32}.issubset(seen)
-    # a batch the layout accepts with several games per lane still steps exactly, all units reporting
-    B, K = 200000, 3
+    assert {16, 64}.issubset(seen) and cap >= 262144
+    # a batch the lane kernel takes, ragged in its last unit, still steps exactly, all units reporting
+    B, K = 200001, 3
     units, gpu = ops.step_stream_layout(B, 4, DEV)
     tok, tgt = ops.gen_demos(B, 4, K, DEV, seed=3)
     st = ops.alloc_states(B, 4, DEV)
@@ -1590,6 +1594,81 @@ def test_step_stream_layout_never_exceeds_what_the_device_keeps_resident():
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
     ops.step_stream(st, tok.permute(1, 0, 2).contiguous(), progress=prog, status=status)
     assert not bool(st.any()) and bool((prog == K).all()) and int(status[0]) == 0
+
+
+@pytest.mark.parametrize("B,K", [(57344, 5), (65536 + 37, 19), (131072, 9)])
+def test_step_stream_one_game_per_lane_equals_k_single_steps(B, K):
+    """Round 4: s4_stream_kernel_lanes (a lane owns a game, 64 games per wavefront, tokens double-buffered, the state leaving
+    transposed through LDS): every step equals the oracle -- state, done[k], sticky overflow -- with terminal games, an
+    overflowing game, wide factors (the whole wavefront then takes the general form on its LDS image), dense actions, a
+    ragged last unit, more steps than two blocks, ready words pre-set and absent."""
+    S = 4
+    rng = np.random.default_rng(B + K)
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(K, B, 3 * S)).astype(np.int8)
+    st[1000:1064] = rng.integers(-120, 121, size=(64, S, S, S))            # large entries: L1 norm beyond the digit form's limit
+    st[::5] = O.action_to_tensor(ac[0, ::5]).astype(np.int8)              # these are done after step 0
+    st[3] = 127
+    ac[1, 3] = 0                                                           # factors -1: 127 - (-1) overflows at step 1
+    ac[2, 2] = rng.integers(-3, 6, size=3 * S)                             # wide factors: the general form, wavefront 0
+    ac[K - 1, 1::4] = rng.integers(0, 3, size=ac[K - 1, 1::4].shape)       # dense actions
+    assert (B - 1) % 5
+    ac[:, B - 1] = rng.integers(-128, 128, size=(K, 3 * S))                # the last game: full-range tokens at every step
+    want_done, want_ovf, cur = np.zeros((K, B), np.uint8), np.zeros(B, np.uint8), st.copy()
+    for k in range(K):
+        cur, d, o = O.step_i8(cur, ac[k])
+        want_done[k] = d
+        want_ovf |= o
+    n_units, gpu = ops.step_stream_layout(B, S, DEV)
+    assert gpu == 64 and n_units == -(-B // 64)
+    acd = dev(ac)
+    for ready in (None, torch.ones(K, dtype=torch.int32, device=DEV)):
+        t = padded(st)
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        prog = torch.zeros(n_units, dtype=torch.int32, device=DEV)
+        status = torch.zeros(1, dtype=torch.int32, device=DEV)
+        out, done = ops.step_stream(t, acd, overflow=ovf, ready=ready, progress=prog, status=status)
+        torch.cuda.synchronize()
+        assert np.array_equal(host(t), cur) and np.array_equal(host(done), want_done) and np.array_equal(host(ovf), want_ovf)
+        assert bool((prog == K).all()) and int(status[0]) == 0
+    assert want_done[0, ::5].all() and want_ovf[3] == 1
+
+
+def test_step_stream_one_game_per_lane_with_a_producer_in_bursts():
+    """The lane kernel's protocol: ready words pre-set with GAPS, the rest released in bursts from a high-priority stream
+    while 65 536 games are resident; a consumer that waits for progress sees the state of every published step."""
+    S, B, K = 4, 65536, 27
+    rng = np.random.default_rng(77)
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(K, B, 3 * S)).astype(np.int8)
+    want_done, cur = np.zeros((K, B), np.uint8), st.copy()
+    for k in range(K):
+        cur, want_done[k], _ = O.step_i8(cur, ac[k])
+    t, acd = padded(st), dev(ac)
+    ready = torch.zeros(K, dtype=torch.int32, device=DEV)
+    ready[:3] = 1
+    ready[4:6] = 1                                                        # behind the gap at 3: not to be taken yet
+    ready[K - 1] = 1
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    n_units, gpu = ops.step_stream_layout(B, S, DEV)
+    assert gpu == 64
+    prog = torch.zeros(n_units, dtype=torch.int32, device=DEV)
+    done = torch.zeros((K, B), dtype=torch.uint8, device=DEV)
+    torch.cuda.synchronize()
+    side, prod = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+    with torch.cuda.stream(side):
+        ops.step_stream(t, acd, done=done, ready=ready, progress=prog, status=status)
+    with torch.cuda.stream(prod):
+        k = 3
+        for burst in (1, 4, 2, 9, 1, 3, 8, 8):
+            ready[k:min(K, k + burst)].fill_(1)
+            prod.synchronize()
+            k += burst
+            if k >= K:
+                break
+    side.synchronize()
+    assert int(status[0]) == 0, "the stepper gave up waiting although every step was released"
+    assert np.array_equal(host(t), cur) and np.array_equal(host(done), want_done) and bool((prog == K).all())
 
 
 # ------------------------------------------------------------------ change of basis on the matrix cores

@@ -3,7 +3,7 @@
 written at the end of the statement as far as hipcc knows, so the compiler may read, copy or spill it before the data has
 arrived.  The kernels tie those registers to their counted wait ("+v"), which pins ORDER, not register allocation: this
 script compiles tg_kernels.hip to assembly and checks, for every s4 / s16 stream kernel, that no instruction between an
-`sc1` load and the next arrival wait (vmcnt <= 2) touches the load's destination, and that the kernels use no scratch.
+`sc1` load and the next arrival wait (vmcnt <= 2; <= 13 in the double-buffered lane kernel) touches the load's destination, and that the kernels use no scratch.
 (s25_stream_kernel receives its tokens by LDS-DMA: no VGPR destination; it is checked for having no VGPR sc1 loads
 outside the compiler-visible polls, which are followed by vmcnt(0).)
     python tools/audit_pending_loads.py        exit code 0 = clean"""
@@ -44,12 +44,12 @@ def kernel_body(src, name):
 def audit(src):
     problems = []
     names = [l.split(":")[0] for l in src if re.match(r"^_ZN2tg\d+s(4|16)_stream_kernel\w*:", l)]
-    if len(names) < 5:
-        problems.append(f"expected five s4/s16 stream kernels, found {len(names)}")
+    if len(names) < 6:
+        problems.append(f"expected six s4/s16 stream kernels, found {len(names)}")
     for nm in names:
         pend = {}
         for idx, t in enumerate(kernel_body(src, nm)):
-            m = re.match(r"global_load_(?:dword|dwordx4|sbyte|ubyte) (v\[?(\d+)(?::(\d+))?\]?), .*\bsc1\b", t)
+            m = re.match(r"global_load_(?:dword|dwordx3|dwordx4|sbyte|ubyte) (v\[?(\d+)(?::(\d+))?\]?), .*\bsc1\b", t)
             if m:
                 lo = int(m.group(2))
                 hi = int(m.group(3)) if m.group(3) else lo
@@ -57,7 +57,10 @@ def audit(src):
                 continue
             w = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", t)
             if w:
-                if int(w.group(1)) <= 2:
+                # arrival waits: vmcnt <= 2 (the loads are the youngest operations); the one-game-per-lane kernel requests the
+                # NEXT block's tokens before it works on this one, so its arrival waits leave this block's D + 4 stores and
+                # a progress store outstanding (vmcnt 12 / 13); its publish waits (20 / 21) are not arrival waits
+                if int(w.group(1)) <= (13 if "lanes" in nm else 2):
                     pend = {}
                 continue
             if not pend:
