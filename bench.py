@@ -992,10 +992,27 @@ def also_lines(S_main, B_main, dev, mode, hbm_copy=None):
 
 
 def fused_lines(dev, batches=(65536, 1 << 20)):
-    """SURVEY N1 / N2 fused entries against the two calls they replace (S=4: the shape MCTS expansion runs at)."""
+    """SURVEY N1 / N2 fused entries against the two calls they replace (S=4: the shape MCTS expansion runs at; S=16: the
+    metric's other size, keys only)."""
     from mat_mul_amd import ops
 
     also = []
+    for s2, b2, k2, reps in ((16, 8192, 8, 5),):
+        tok, tgt = ops.gen_demos(b2, s2, k2, dev, seed=6)
+        kids = ops.alloc_states(b2 * k2, s2, dev).unflatten(0, (b2, k2))
+        kd = torch.zeros((b2, k2), dtype=torch.uint8, device=dev)
+        kc = torch.zeros((b2, k2), dtype=torch.uint8, device=dev)
+        keys = torch.zeros((b2, k2), dtype=torch.int64, device=dev)
+        fused = graph_time(lambda: ops.expand(tgt, tok, out=kids, done=kd, changed=kc, keys=keys), dev, reps=reps)
+        kf = keys.clone()
+        two = graph_time(lambda: (ops.expand(tgt, tok, out=kids, done=kd, changed=kc),
+                                  keys.view(-1).copy_(ops.state_hash(kids.flatten(0, 1)))), dev, reps=reps)
+        also.append({"workload": f"N2 FUSED tg_expand_keyed_i8: S={s2} batch={b2}, k={k2}: children + their 64-bit keys in one "
+                                 f"launch (extend_tree's state_to_str per child, act.py:188-190)",
+                     "ok": bool(torch.equal(keys, kf)), "us_per_launch": round(fused * 1e6, 2),
+                     "us_expand_then_hash": round(two * 1e6, 2), "gain": round(two / fused, 3)})
+        del kids, kd, kc, keys, tok, tgt
+        torch.cuda.empty_cache()
     for b2 in batches:
         s2, T, k2 = 4, 4, 8
         reps = 20 if b2 <= 65536 else 5

@@ -2666,13 +2666,22 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
     // chunks per lane): measured 0.48 of the HBM peak at 2^19 games against 0.43 (TS=32) and 0.29 (TS=64)
     if (a.S == 9) TG_PACKED(9, 16);
     if constexpr (MODE == EXPAND) {
-      if (a.S == 16 && a.stream_out) {  // children of 128 MiB and more: non-temporal stores
+      // S = 16: children of 128 MiB and more leave by non-temporal stores; with keys asked for (tg_expand_keyed_i8) they
+      // are formed in the same launch while a child is in registers
+      const bool keyed = a.keys != nullptr && !TG_SWITCH("TG_EXPAND_KEYS_UNFUSED");
+      if (a.S == 16 && (a.stream_out || keyed)) {
         const int64_t blocks = (B + PGeo<16, 64>::GPB - 1) / PGeo<16, 64>::GPB;
         if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
         const int at = a.nact < PGeo<16, 64>::ATILE ? a.nact : PGeo<16, 64>::ATILE;
         const int ldsb = packed_lds_bytes<16, 64, MODE>(at);
         (void)hipGetLastError();
-        hipLaunchKernelGGL((packed_kernel<16, 64, MODE, true>), dim3((unsigned)blocks), dim3(kBlock), ldsb, st, a, flim, at);
+        if (keyed) {
+          if (a.stream_out) hipLaunchKernelGGL((packed_kernel<16, 64, MODE, true, true>), dim3((unsigned)blocks), dim3(kBlock), ldsb, st, a, flim, at);
+          else hipLaunchKernelGGL((packed_kernel<16, 64, MODE, false, true>), dim3((unsigned)blocks), dim3(kBlock), ldsb, st, a, flim, at);
+          if (keys_fused) *keys_fused = true;
+        } else {
+          hipLaunchKernelGGL((packed_kernel<16, 64, MODE, true>), dim3((unsigned)blocks), dim3(kBlock), ldsb, st, a, flim, at);
+        }
         return check_launch(fn);
       }
     }

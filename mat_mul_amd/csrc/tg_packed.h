@@ -199,9 +199,13 @@ constexpr int packed_lds_bytes(int at) {
 
 // NTS (EXPAND at S = 16 only): the children leave by non-temporal stores (268 MB of children: 56.5 -> 50.6 us; the
 // 15 625-byte children of S = 25 end in partial lines and lose with them: 124 -> 134 us).
-template <int S, int TS, int MODE, bool NTS = false>
+// KEYS (round 4; EXPAND at S = 16, tg_expand_keyed_i8): the 64-bit key of every child is formed while the child is in
+// registers -- extend_tree filters every expansion against the tree (act.py:183-195), and a second pass re-reads the
+// 268 MB of children it has just written (8 192 parents x 8).  A team is a wavefront here: the chunk sums meet by shuffles.
+template <int S, int TS, int MODE, bool NTS = false, bool KEYS = false>
 __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, int at) {
   using G = PGeo<S, TS>;
+  static_assert(!KEYS || (MODE == EXPAND && TS == 64 && G::TAIL == 0), "keys are formed by the wavefront-per-parent expansion");
   constexpr bool SUB = (MODE != GENF);  // STEP, MANY, EXPAND subtract
   extern __shared__ __attribute__((aligned(16))) short lds[];
   const int raw_stride = (at * 3 * S + 8 + 3) & ~3;  // bytes of raw tokens per team
@@ -278,6 +282,20 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
     for (int t = 0; t < G::GPB; ++t) {
       const int64_t b = static_cast<int64_t>(blockIdx.x) * G::GPB + t;
       if (b < a.B && flagged_or_all<MODE>(a, b)) slow_game<MODE>(a, b, flags);
+    }
+    if constexpr (KEYS) {  // the exact form wrote the children to memory: every team keys those of its parent from there
+      __syncthreads();
+      if (live) {
+        for (int k = 0; k < a.nact; ++k) {
+          const int64_t child = g * a.nact + k;
+          uint64_t hk = 0;
+#pragma unroll
+          for (int n = 0; n < G::NCH; ++n)
+            if (cv[n]) hk += hash_chunk(*reinterpret_cast<const uint4*>(a.out + child * a.out_stride + 16 * (lt + G::TSA * n)), lt + G::TSA * n);
+          for (int off = 32; off > 0; off >>= 1) hk += __shfl_xor(hk, off);
+          if (lt == 0) a.keys[child] = hash_finish(hk, S * S * S);
+        }
+      }
     }
     return;
   }
@@ -522,6 +540,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
         for (int n = 0; n < G::NCH; ++n) unpack_pairs(par[n], A[n]);
         apply(F + k * G::FSTRIDE, A);
         uint32_t nz = 0, covf = 0;
+        uint64_t hk = 0;
 #pragma unroll
         for (int n = 0; n < G::NCH; ++n) {
           const uint4 q = pack_pairs(A[n], nz, covf);
@@ -531,6 +550,13 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
             if constexpr (NTS && G::TAIL == 0) store16_nt(dp, q);
             else store_chunk<G::TAIL>(dp, q, ctail[n]);
           }
+          if constexpr (KEYS) {
+            if (cv[n]) hk += hash_chunk(q, lt + G::TSA * n);
+          }
+        }
+        if constexpr (KEYS) {
+          for (int off = 32; off > 0; off >>= 1) hk += __shfl_xor(hk, off);
+          if (lt == 0 && live) a.keys[child] = hash_finish(hk, S * S * S);
         }
         if (nz) nzF[k] = 1;
         if (covf & 0xFF00FF00u) ovF[k] = 1;

@@ -23,10 +23,15 @@ class TensorGameEnv:
 
     Args mirror the reference's flags: ``dim_3d`` (training.py:83), ``shift`` (utils.py:56).
     ``game_id_offset`` is the global id of local game 0 (sharded runs, section 8e).
+    ``track_nnz``: True / False force, None (default) = by batch size (``TRACKED_FROM``): the env then carries every
+    game's count of non-zero entries and ``step()`` loads only the rows an action touches.  The count belongs to the
+    env: code that writes ``env.state`` directly (instead of ``reset()``) must call ``recount()`` afterwards.
     """
 
+    TRACKED_FROM = {16: 12000, 25: 2048}  # games from which step() takes tg_step_tracked_i8 when track_nnz is left to the env
+
     def __init__(self, batch_size: int, dim_3d: int, device="cuda", shift: int = 1,
-                 track_overflow: bool = True, game_id_offset: int = 0, dim_t: int = 1, track_nnz: bool = False):
+                 track_overflow: bool = True, game_id_offset: int = 0, dim_t: int = 1, track_nnz: Optional[bool] = None):
         self.B, self.S, self.shift = int(batch_size), int(dim_3d), int(shift)
         self.T = int(dim_t)  # history depth (reference --dim_t, training.py:75); 1 = head only
         self.device = torch.device(device)
@@ -43,8 +48,14 @@ class TensorGameEnv:
         # track_nnz (dim_t == 1): the env carries every game's number of non-zero entries and steps with
         # ``tg_step_tracked_i8``, which loads only the rows an action touches (S = 16, 25: 1.1-1.9x from a few thousand games
         # on); ``nnz()`` then costs nothing.  Whoever writes ``state`` behind the env's back must call ``recount()``.
+        # track_nnz=None (default) decides by the measured crossovers: the tracked step pays two
+        # dependent round trips for ~30 % of the lines, so it wins once the batch no longer fits one round of wavefronts --
+        # S = 16 from 12 000 games on (8 192: 5.96 against 5.39 us; 12 288: 8.4 against 11.1), S = 25 from 2 048 (10.0
+        # against 10.7; 4 096: 12.5 against 13.8; 2 GiB of states: 300 against 574) -- and only when dim_t == 1.
         if track_nnz and self.T != 1:
             raise TensorGameError("TensorGameEnv", -1, "track_nnz needs dim_t == 1 (the tracked step is in place)")
+        if track_nnz is None:
+            track_nnz = self.T == 1 and self.B >= self.TRACKED_FROM.get(self.S, 1 << 62)
         self._nnz = torch.zeros((self.B,), dtype=torch.int32, device=self.device) if track_nnz else None
 
     @property

@@ -172,6 +172,31 @@ def test_env_track_nnz_matches_the_plain_env():
         TensorGameEnv(4, 4, DEV, dim_t=2, track_nnz=True)
 
 
+@pytest.mark.parametrize("S,below,above", [(16, 11999, 12000), (25, 2047, 2048)])
+def test_env_picks_the_tracked_step_by_batch_size(S, below, above):
+    """TensorGameEnv(track_nnz=None) takes tg_step_tracked_i8 from the measured crossovers on (S=16:
+    12 000 games, S=25: 2 048) when dim_t == 1 -- both sides of each crossover roll a demonstration out to zero with the
+    same states, done flags and counts as an env forced the other way; dim_t > 1 and S=4 never track."""
+    R = 6
+    for B in (below, above):
+        auto = TensorGameEnv(B, S, DEV)
+        assert (auto._nnz is not None) == (B == above)
+        forced = TensorGameEnv(B, S, DEV, track_nnz=(B != above))       # the other kernel
+        tok, tgt = ops.gen_demos(B, S, R, DEV, seed=B)
+        auto.reset(tgt)
+        forced.reset(tgt)
+        assert torch.equal(auto.nnz(), forced.nnz())
+        for k in range(R):
+            sa, da = auto.step(tok[:, k].contiguous())
+            sf, df = forced.step(tok[:, k].contiguous())
+            assert torch.equal(da, df) and torch.equal(auto.nnz(), forced.nnz()), (B, k)
+        assert torch.equal(auto.state, forced.state) and not bool(auto.state.any()) and bool(auto.done.all())
+        del auto, forced, tok, tgt
+        torch.cuda.empty_cache()
+    assert TensorGameEnv(above, S, DEV, dim_t=2)._nnz is None and TensorGameEnv(1 << 16, 4, DEV)._nnz is None
+    assert TensorGameEnv(above, S, DEV, track_nnz=False)._nnz is None
+
+
 def test_step_tracked_replays_a_demo_to_zero():
     """BASELINE config 5's shape at a size the oracle is not needed for: generate, then replay the demo's own actions with
     the tracked step -- every game ends all zero with nnz = 0 and done = 1 exactly at the last action."""
@@ -703,16 +728,16 @@ def test_full_size_generate_replay_terminate(S, B, R):
     zero exactly at the last step (generator, step, step_many and done agree)."""
     demos = SyntheticDemos(R, B, 1, S, DEV, seed=S)
     assert not bool(demos.overflow.any())
-    env = TensorGameEnv(B, S, DEV)
-    env.reset(demos.target_tensor)
     rev = demos.action_seq.flip(1).contiguous()
-    for k in range(R):
-        state, done = env.step(rev[:, k])
-        if k < R - 1:
-            # a game may reach zero early only if the remaining terms cancel; it must then leave zero again
-            pass
-    assert bool(done.all()) and not bool(state.any()) and not env.any_overflow()
-    assert int(env.nnz().sum()) == 0
+    # track_nnz=False: tg_step_i8 in the variant this footprint selects (whole lines, non-temporal loads, ...); then the env
+    # as a user gets it (from 12 000 games at S=16 / 2 048 at S=25 it carries nnz and takes the tracked step)
+    for track in (False, None):
+        env = TensorGameEnv(B, S, DEV, track_nnz=track)
+        env.reset(demos.target_tensor)
+        for k in range(R):
+            state, done = env.step(rev[:, k])   # (a game may reach zero early only if the remaining terms cancel)
+        assert bool(done.all()) and not bool(state.any()) and not env.any_overflow()
+        assert int(env.nnz().sum()) == 0
     env.reset(demos.target_tensor)
     state, done_step = env.step_many(demos.action_seq)
     assert not bool(state.any()) and bool((done_step >= 0).all()) and int(done_step.max()) == R - 1

@@ -96,6 +96,30 @@ def test_seen_full_table_sets_status_and_loses_nothing_silently():
     assert int((fresh == 0).sum()) == 8
 
 
+@pytest.mark.parametrize("B,k", [(1, 1), (5, 8), (131, 3), (37, 70), (2048, 8)])
+def test_expand_keys_fused_at_s16(B, k):
+    """Round 4: at S=16 tg_expand_keyed_i8 forms the keys inside the expansion kernel (packed_kernel<16, 64, EXPAND, *, true>):
+    ragged batches, more actions than one staging tile, null actions, overflowing children, and parents whose factors are
+    beyond the packed form (the workgroup's exact fallback writes the children, then keys them from memory) -- keys ==
+    tg_hash_u64 of the children == the oracle's key, children / done / changed == the oracle."""
+    S = 16
+    rng = np.random.default_rng(B * 100 + k)
+    st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, k, 3 * S)).astype(np.int8)
+    ac[::3, 0, :S] = 1                                                  # null actions (u = 0)
+    if B > 4:
+        st[2] = 127                                                     # children of game 2 overflow
+        ac[4, k - 1] = rng.integers(-128, 128, size=3 * S)              # factors beyond the packed form: exact fallback of its workgroup
+    kids_o, done_o, changed_o, ovf_o = O.expand_i8(st, ac)
+    want = O.state_hash(kids_o.reshape(B * k, S, S, S)).reshape(B, k)
+    ovf = torch.zeros((B, k), dtype=torch.uint8, device=DEV)
+    kids, done, changed, keys = ops.expand(padded(st), dev(ac), want_keys=True, overflow=ovf)
+    assert np.array_equal(host(kids), kids_o) and np.array_equal(host(done), done_o) and np.array_equal(host(changed), changed_o)
+    assert np.array_equal(host(ovf), ovf_o)
+    assert np.array_equal(host(keys).view(np.uint64), want)
+    assert np.array_equal(host(ops.state_hash(kids.flatten(0, 1))).view(np.uint64), want.reshape(-1))
+
+
 def test_expand_keys_match_state_hash():
     """want_keys of expand == state_hash of the children it wrote, every kernel family, packed and byte-offset layouts."""
     rng = np.random.default_rng(17)
