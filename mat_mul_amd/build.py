@@ -25,6 +25,14 @@ OBJ_DIR = LIB_DIR / "obj"
 LIB_PATH = LIB_DIR / "libtensorgame.so"
 LIB_PATH_AB = LIB_DIR / "libtensorgame_ab.so"
 LIB_PATH_STAMPS = LIB_DIR / "libtensorgame_stamps.so"  # ab + in-kernel s_memtime stamps (tools/stamp_genfused.py); never shipped
+# The HOST half of the library (validation, dispatch, occupancy caches, error strings: everything outside the kernels) under
+# AddressSanitizer + UndefinedBehaviorSanitizer: `-fsanitize=address,undefined -fno-gpu-sanitize` instruments the host pass
+# only (the device pass compiles as usual: the host objects need its code object to link; GPU ASan is not available on
+# this pool).  CPU build container only (tests/test_host_sanitizer_cpu.py); never loaded by the package, never shipped.
+LIB_PATH_HOSTASAN = LIB_DIR / "libtensorgame_hostasan.so"
+SAN_FLAGS = ["-O1", "-g", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form",
+             "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+             "-Wall", "-Wno-unused-function"]
 SOURCES = sorted(CSRC.glob("*.hip"))
 HEADERS = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "tensor_game.h"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
@@ -40,7 +48,21 @@ def _hipcc() -> str:
 
 
 def lib_path(ab=False) -> Path:
+    if ab == "hostasan":
+        return LIB_PATH_HOSTASAN
     return LIB_PATH_STAMPS if ab == "stamps" else (LIB_PATH_AB if ab else LIB_PATH)
+
+
+def asan_runtime() -> Path | None:
+    """clang's shared AddressSanitizer runtime next to hipcc's clang (to LD_PRELOAD into a python that loads the
+    sanitized library), or None."""
+    res = subprocess.run([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    p = Path(res.stdout.strip()) if res.returncode == 0 else None
+    if p and p.is_absolute() and p.exists():
+        return p
+    for cand in sorted(Path("/opt/rocm/lib/llvm/lib/clang").glob("*/lib/linux/libclang_rt.asan-x86_64.so")):
+        return cand
+    return None
 
 
 def _newest_input() -> float:
@@ -53,7 +75,7 @@ def is_stale(ab=False) -> bool:
 
 
 def _obj(src: Path, ab) -> Path:
-    return OBJ_DIR / f"{src.stem}{'.stamps' if ab == 'stamps' else '.ab' if ab else ''}.o"
+    return OBJ_DIR / f"{src.stem}{'.hostasan' if ab == 'hostasan' else '.stamps' if ab == 'stamps' else '.ab' if ab else ''}.o"
 
 
 def build(force: bool = False, verbose: bool = False, ab=False) -> Path:
@@ -64,13 +86,13 @@ def build(force: bool = False, verbose: bool = False, ab=False) -> Path:
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
     hipcc = _hipcc()
     hdr_time = max(p.stat().st_mtime for p in HEADERS + [Path(__file__)])
-    extra = ["-DTG_AB_SWITCHES", "-DTG_STAMPS"] if ab == "stamps" else (["-DTG_AB_SWITCHES"] if ab else [])
+    extra = ["-DTG_AB_SWITCHES", "-DTG_STAMPS"] if ab == "stamps" else ([] if ab == "hostasan" else ["-DTG_AB_SWITCHES"] if ab else [])
 
     def compile_one(src: Path):
         obj = _obj(src, ab)
         if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_time):
             return src, 0.0, None
-        cmd = [hipcc, *FLAGS, *extra, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *(SAN_FLAGS if ab == "hostasan" else FLAGS), *extra, "-c", str(src), "-o", str(obj)]
         t0 = time.perf_counter()
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
@@ -87,6 +109,8 @@ def build(force: bool = False, verbose: bool = False, ab=False) -> Path:
         if verbose:
             print(f"  {src.name}: {'up to date' if dt == 0.0 else f'{dt:.1f} s'}")
     cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *[str(_obj(s, ab)) for s in SOURCES], "-o", str(lib)]
+    if ab == "hostasan":
+        cmd += ["-fsanitize=address,undefined", "-shared-libasan"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -99,4 +123,4 @@ if __name__ == "__main__":
     import sys
 
     print(build(force="--force" in sys.argv, verbose=True,
-                ab="stamps" if "--stamps" in sys.argv else "--ab" in sys.argv))
+                ab="hostasan" if "--hostasan" in sys.argv else "stamps" if "--stamps" in sys.argv else "--ab" in sys.argv))
