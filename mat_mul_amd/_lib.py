@@ -8,10 +8,9 @@ from pathlib import Path
 
 # TG_LIB_VARIANT=ab selects the A/B build (libtensorgame_ab.so, -DTG_AB_SWITCHES: the same entry points plus the
 # TG_* environment switches that force a kernel variant) -- measurement and A/B tests only.
-_VARIANT = os.environ.get("TG_LIB_VARIANT", "")  # "", "ab", or "stamps" (ab + in-kernel time stamps; diagnostics only)
-AB_VARIANT = _VARIANT in ("ab", "stamps")
-LIB_PATH = Path(__file__).resolve().parent / "lib" / {"ab": "libtensorgame_ab.so", "stamps": "libtensorgame_stamps.so"}.get(
-    _VARIANT, "libtensorgame.so")
+_VARIANT = os.environ.get("TG_LIB_VARIANT", "")  # "" or "ab"
+AB_VARIANT = _VARIANT == "ab"
+LIB_PATH = Path(__file__).resolve().parent / "lib" / ("libtensorgame_ab.so" if AB_VARIANT else "libtensorgame.so")
 
 TG_ABI_VERSION = 4
 TG_MAX_S = 32

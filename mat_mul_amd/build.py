@@ -24,7 +24,6 @@ LIB_DIR = PKG / "lib"
 OBJ_DIR = LIB_DIR / "obj"
 LIB_PATH = LIB_DIR / "libtensorgame.so"
 LIB_PATH_AB = LIB_DIR / "libtensorgame_ab.so"
-LIB_PATH_STAMPS = LIB_DIR / "libtensorgame_stamps.so"  # ab + in-kernel s_memtime stamps (tools/stamp_genfused.py); never shipped
 # The HOST half of the library (validation, dispatch, occupancy caches, error strings: everything outside the kernels) under
 # AddressSanitizer + UndefinedBehaviorSanitizer: `-fsanitize=address,undefined -fno-gpu-sanitize` instruments the host pass
 # only (the device pass compiles as usual: the host objects need its code object to link; GPU ASan is not available on
@@ -50,7 +49,7 @@ def _hipcc() -> str:
 def lib_path(ab=False) -> Path:
     if ab == "hostasan":
         return LIB_PATH_HOSTASAN
-    return LIB_PATH_STAMPS if ab == "stamps" else (LIB_PATH_AB if ab else LIB_PATH)
+    return LIB_PATH_AB if ab else LIB_PATH
 
 
 def asan_runtime() -> Path | None:
@@ -75,7 +74,7 @@ def is_stale(ab=False) -> bool:
 
 
 def _obj(src: Path, ab) -> Path:
-    return OBJ_DIR / f"{src.stem}{'.hostasan' if ab == 'hostasan' else '.stamps' if ab == 'stamps' else '.ab' if ab else ''}.o"
+    return OBJ_DIR / f"{src.stem}{'.hostasan' if ab == 'hostasan' else '.ab' if ab else ''}.o"
 
 
 def build(force: bool = False, verbose: bool = False, ab=False) -> Path:
@@ -86,7 +85,7 @@ def build(force: bool = False, verbose: bool = False, ab=False) -> Path:
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
     hipcc = _hipcc()
     hdr_time = max(p.stat().st_mtime for p in HEADERS + [Path(__file__)])
-    extra = ["-DTG_AB_SWITCHES", "-DTG_STAMPS"] if ab == "stamps" else ([] if ab == "hostasan" else ["-DTG_AB_SWITCHES"] if ab else [])
+    extra = [] if ab == "hostasan" or not ab else ["-DTG_AB_SWITCHES"]
 
     def compile_one(src: Path):
         obj = _obj(src, ab)
@@ -123,4 +122,4 @@ if __name__ == "__main__":
     import sys
 
     print(build(force="--force" in sys.argv, verbose=True,
-                ab="hostasan" if "--hostasan" in sys.argv else "stamps" if "--stamps" in sys.argv else "--ab" in sys.argv))
+                ab="hostasan" if "--hostasan" in sys.argv else "--ab" in sys.argv))

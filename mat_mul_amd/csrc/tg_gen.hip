@@ -543,13 +543,6 @@ struct CBGeo {
 // NW wavefronts per workgroup share the game's LDS: the kernel holds one or two workgroups per CU (the vector fallback's
 // int32 tensor decides the LDS size), so the wavefronts that hide each other's MFMA / LDS latency must come from the
 // workgroup itself.
-// Diagnostic build only (-DTG_STAMPS): workgroups 0, 32, .., 480 record s_memtime at phase boundaries into the overflow buffer
-// (32 uint64 per workgroup; B >= 4096).
-#ifdef TG_STAMPS
-#define TG_CSTAMP(i) do { const int ci_ = (i); if ((blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 16 && threadIdx.x == 0 && overflow && ci_ < 32) reinterpret_cast<unsigned long long*>(overflow)[(blockIdx.x >> 5) * 32 + ci_] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define TG_CSTAMP(i) do {} while (0)
-#endif
 template <int S, int NW>
 __global__ __launch_bounds__(64 * NW) void change_basis_mfma_kernel(const int8_t* in, const int32_t* basis, int8_t* out,
                                                                     uint8_t* overflow, int64_t B, int64_t stride) {
@@ -567,10 +560,7 @@ __global__ __launch_bounds__(64 * NW) void change_basis_mfma_kernel(const int8_t
   constexpr int JP = (S + 3) & ~3;                              // stage 1: rows per i, padded to a multiple of four
   constexpr int NT1 = (S * JP + 31) / 32;                       // stage 1: tiles of 32 rows n' = i JP + j
 
-  int cst = 0;
-  (void)cst;
   for (int64_t g = blockIdx.x; g < B; g += gridDim.x) {
-    TG_CSTAMP(cst++);  // game start
     // ---- 0. state image, int8 matrices (zero padded), eligibility ----
     if (tid < 8) red[tid] = 0;
     for (int e = tid; e < G::MAT / 4; e += kThreads) reinterpret_cast<uint32_t*>(M8)[e] = 0;
@@ -631,7 +621,6 @@ __global__ __launch_bounds__(64 * NW) void change_basis_mfma_kernel(const int8_t
       atomicMax(&red[1 + m], rs);
     }
     __syncthreads();
-    TG_CSTAMP(cst++);  // image + matrices + sums done
     const int rb = red[2], rc = red[3], mx0 = red[5];  // (the last stage's sums are int32: no condition on A's rows)
     // |Y1| <= mx0 rc and |Y2| <= mx0 rc rb must fit the two byte planes (16 bits); workgroup-uniform
     const bool eligible = red[0] == 0 && static_cast<int64_t>(mx0) * rc <= 32639 && static_cast<int64_t>(mx0) * rc * rb <= 32639;
@@ -687,7 +676,6 @@ __global__ __launch_bounds__(64 * NW) void change_basis_mfma_kernel(const int8_t
         }
       }
     }
-    TG_CSTAMP(cst++);  // stage 1 own part
     __syncthreads();
     // (bytes j >= S of a plane row hold shadows or stale bytes: they meet the zero rows k >= S of the B operand)
 
@@ -718,7 +706,6 @@ __global__ __launch_bounds__(64 * NW) void change_basis_mfma_kernel(const int8_t
         }
       }
     }
-    TG_CSTAMP(cst++);  // stage 2 own part
     __syncthreads();
 
     // ---- 3. contract i with A: one tile per c; the matrix is the A operand (rows a), the tile's rows (c,b) the B
@@ -747,7 +734,6 @@ __global__ __launch_bounds__(64 * NW) void change_basis_mfma_kernel(const int8_t
         }
       }
     }
-    TG_CSTAMP(cst++);  // stage 3 own part
     if (__ballot((hi3 > 127) | (lo3 < -128)) != 0 && lane == 0) red[4] = 1;
     __syncthreads();
     {
@@ -756,7 +742,6 @@ __global__ __launch_bounds__(64 * NW) void change_basis_mfma_kernel(const int8_t
         store_chunk16<G::TAIL>(dst + 16 * c, *reinterpret_cast<const uint4*>(img + 16 * c), c == G::NCHUNK - 1);
       if (tid == 0 && overflow && red[4]) overflow[g] = 1;
     }
-    TG_CSTAMP(cst++);  // stores issued
     __syncthreads();
   }
 }

@@ -41,36 +41,10 @@ struct GenArgs {
 #else
 #define TG_GF_ON(bit) true
 #endif
-// Diagnostic build only (-DTG_STAMPS, tools/stamp_genfused.py): workgroups 0, 100, .. 1900 record the shader clock at phase
-// boundaries into the OVERFLOW buffer (24 uint64 per workgroup; B >= 4096), which that build therefore does not use
-// as flags.  Never part of the product or of the A/B library.
-#ifdef TG_STAMPS
-#define TG_STAMP(i)                                                                                             \
-  do {                                                                                                          \
-    const int tg_stamp_i = (i);                                                                                 \
-    if (blockIdx.x % 100 == 0 && blockIdx.x < 2000 && threadIdx.x == 0 && tg_stamp_i < 24 && ga.overflow)       \
-      reinterpret_cast<unsigned long long*>(ga.overflow)[blockIdx.x / 100 * 24 + tg_stamp_i] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-// the same for lane 0 of the LAST wavefront (a storing one), slots 12 .. 23
-#define TG_STAMP_LAST(i)                                                                                        \
-  do {                                                                                                          \
-    const int tg_stamp_i = 12 + (i);                                                                            \
-    if (blockIdx.x % 100 == 0 && blockIdx.x < 2000 && threadIdx.x == blockDim.x - 64 && tg_stamp_i < 24 && ga.overflow) \
-      reinterpret_cast<unsigned long long*>(ga.overflow)[blockIdx.x / 100 * 24 + tg_stamp_i] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define TG_STAMP(i) \
-  do {              \
-  } while (0)
-#define TG_STAMP_LAST(i) \
-  do {                   \
-  } while (0)
-#endif
-
-// (token images: only with a basis -- without one the drawn tokens go from registers straight to global memory)
+// T, the target image, the four OR words (no token image: a lane's tokens leave from its registers)
 template <int S>
-constexpr int genfused_lds_bytes(int Rp, int R, bool basis) {
-  return MGeo<S>::TROWS * (Rp + 16) + MGeo<S>::IMG + 32 + (basis ? 2 * (((R * 3 * S + 15) & ~15) + 16) : 0) + 16;
+constexpr int genfused_lds_bytes(int Rp) {
+  return MGeo<S>::TROWS * (Rp + 16) + MGeo<S>::IMG + 32 + 16;
 }
 
 // bytes 16h .. 16h+15 of an S-byte row in global memory (any alignment; nothing past the row is read; bytes >= S are 0).
@@ -130,7 +104,8 @@ __device__ __forceinline__ int exact_target_from_tokens(const uint8_t* tok, int 
 // fewest draw jobs of the next game (3 Rp/32 jobs over 4 wavefronts: at R = 64 two wavefronts draw twice, the other two
 // draw once and store), so the memory phase hides behind the next game's Philox arithmetic.  The target image and T are
 // free again at B1 / B2 respectively.  (Round 2 also kept a double-buffered token image in LDS; since round 3 a lane's
-// tokens leave from its registers inside the draw phase -- DIRECT below -- and the image exists in the A/B library only.)
+// tokens leave from its registers inside the draw phase by unaligned global stores: the image cost 16 ds_write_b8 + 6 shifts
+// per job and lane and a second pass LDS -> global -- 4.1 + 1.0 us of 32.3 by ablation; it was removed in round 4.)
 //
 // NW wavefronts per workgroup: 4, or 6 when the 3 Rp/32 draw jobs divide by 6 (R = 64: one job per wavefront instead of
 // two wavefronts drawing twice while two wait, and 20 tiles as 4+4+3+3+3+3 instead of 5 each).
@@ -140,9 +115,7 @@ __device__ __forceinline__ int exact_target_from_tokens(const uint8_t* tok, int 
 // LUT (round 3; host-proved: TERN, no basis, no CHECK, values exactly (-1, 0, 1)): the u and v rows of T hold the
 // ternary codes of lutmul16 (tg_mfma.h) and the tiles look their byte products up -- 8 VALU instructions per 32
 // actions and tile instead of 16 (the byte products were ~40 % of this kernel's instructions).
-// DIRECT (round 3): a lane's tokens leave by unaligned global stores from its registers; false = the token image in LDS + a
-// second pass LDS -> global (kept for the A/B library: TG_GF_TOKIMG).
-template <int S, int KS, bool BASIS, int NW, bool CHECK = true, bool TERN = false, bool LUT = false, bool DIRECT = true>
+template <int S, int KS, bool BASIS, int NW, bool CHECK = true, bool TERN = false, bool LUT = false>
 __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) {
   static_assert(!LUT || (TERN && !BASIS && !CHECK), "the lookup form is for the plain ternary generator");
   using G = MGeo<S>;
@@ -151,18 +124,11 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
   if constexpr (KS != 0) Rp = 32 * KS;
   const int RS = Rp + 16;
   const int R = ga.R, blk = R * G::A3;
-  // [pad + blk] bytes; pad = the block's 16-byte phase in global memory.  Without a basis there is no token image: a
-  // lane's drawn tokens are final as they stand and leave by (unaligned) global stores from its registers -- the image
-  // cost 16 ds_write_b8 + 6 shifts per job and lane and a second pass LDS -> global (round 3: the draw's LDS writes
-  // were 4.1 us and the token stores 1.0 us of 32.3 by ablation)
-  const int tokbuf_bytes = DIRECT ? 0 : ((blk + 15) & ~15) + 16;
   int8_t* const T = reinterpret_cast<int8_t*>(mfma_smem);
   uint8_t* const img = mfma_smem + G::TROWS * RS;
-  uint8_t* const tokimg = img + G::IMG + 32;  // two buffers of tokbuf_bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
   if (static_cast<int64_t>(blockIdx.x) >= ga.B) return;
-  TG_STAMP(0);
   if (!TG_GF_ON(32)) return;  // (A/B build: launch + dispatch only)
 
   // T starts all zero and only cells (x, i < S, r < R) are ever written: W rows l >= S and the padding actions
@@ -196,10 +162,8 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
   const bool light = wave >= nheavy;
   const int light_tid = tid - 64 * nheavy, light_threads = NTHREADS - 64 * nheavy;
 
-  auto token_pad = [&](int64_t g) { return static_cast<int>(reinterpret_cast<uintptr_t>(ga.actions + g * blk) & 15); };
-
-  // ---- draw (and transform) the factors of game g: registers -> T and the token image `tk` ----
-  auto draw = [&](int64_t g, uint8_t* tk, int& big, int& bad) {
+  // ---- draw (and transform) the factors of game g: registers -> T, the tokens -> global memory ----
+  auto draw = [&](int64_t g, int& big, int& bad) {
     if (!TG_GF_ON(64)) return;  // (A/B build: no draw phase at all)
     const uint64_t gid = ga.gid0 + static_cast<uint64_t>(g);
     for (int job = wave; job < njob; job += NW) {
@@ -290,17 +254,7 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
             for (int k = KBOTH; k < KLOW; ++k) tcol[k * RS] = static_cast<int8_t>(static_cast<uint32_t>(F[k >> 2]) >> (8 * (k & 3)));
           }
         }
-        if constexpr (!DIRECT) {
-          if (active && holds && TG_GF_ON(2)) {
-            uint8_t* const trow = tk + (3 * r + x) * S + kbase;
-#pragma unroll
-            for (int k = 0; k < KBOTH; ++k) trow[k] = static_cast<uint8_t>(static_cast<uint32_t>(K[k >> 2]) >> (8 * (k & 3)));
-            if (kbase == 0) {
-#pragma unroll
-              for (int k = KBOTH; k < KLOW; ++k) trow[k] = static_cast<uint8_t>(static_cast<uint32_t>(K[k >> 2]) >> (8 * (k & 3)));
-            }
-          }
-        } else if (active && holds && TG_GF_ON(16)) {
+        if (active && holds && TG_GF_ON(16)) {
           // the vector's tokens: KLOW bytes (lane half 0) / KBOTH bytes (lane half 1) at (3 r + x) S + kbase of the game's
           // block, any alignment: whole dwords as unaligned global stores, then the tail bytes
           // As FEW store instructions and lane transactions as possible: these stores are scattered (a lane's bytes lie 3 S
@@ -331,8 +285,6 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, F, acc, 0, 0, 0);
         if (active && TG_GF_ON(2)) {
           int8_t* const tcol = T + (x * S + 4 * h) * RS + r;
-          uint8_t* const trow = DIRECT ? nullptr : tk + (3 * r + x) * S + 4 * h;
-          (void)trow;
           const int lim = x < 2 ? G::UVLIM : 127, lim_lo = x < 2 ? -G::UVLIM : -128;
           int fmx = 0, fmn = 0;  // range of the emitted factors: ONE test per job instead of five operations per value
           auto emit = [&](int t) {  // register t = row a0 + 4 h, a0 = (t & 3) + 8 (t >> 2)
@@ -341,9 +293,8 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
             fmx = max(fmx, f);
             fmn = min(fmn, f);
             tcol[a0 * RS] = static_cast<int8_t>(f);
-            if constexpr (!DIRECT) trow[a0] = static_cast<uint8_t>(f + ga.shift);
           };
-          if constexpr (DIRECT) {
+          {
             // The tokens straight to global memory, in as few store instructions as the plain generator's (scattered stores
             // are paid per instruction): register group q holds the four consecutive rows 8 q + 4 h + (0..3); two
             // v_permlane32_swap hand the lower lane half rows 0..15 and the upper half rows 16..31 of the action's vector,
@@ -416,33 +367,21 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
     }
   };
 
-  // ---- LDS images of game g -> global memory, by threads t = 0 .. nthr-1: target (unless the exact path already wrote
-  // it) as 16-byte chunks; tokens = the block's bytes [pad, pad + blk) of the image, aligned 16-byte chunks inside ----
-  auto store_outputs = [&](int64_t g, const uint8_t* tbuf, bool with_target, int t, int nthr) {
+  // ---- the target image of game g -> global memory as 16-byte chunks, by threads t = 0 .. nthr-1 (unless the exact path
+  // already wrote it) ----
+  auto store_outputs = [&](int64_t g, bool with_target, int t, int nthr) {
     if (with_target && TG_GF_ON(8)) {
       int8_t* const out = ga.target + g * ga.out_stride;
       constexpr int NFULL = G::TAIL ? G::NCHUNK - 1 : G::NCHUNK;  // whole 16-byte chunks
       copy_chunks(img, reinterpret_cast<uint8_t*>(out), NFULL, t, nthr);
       if (G::TAIL != 0 && t < G::TAIL) out[16 * NFULL + t] = static_cast<int8_t>(img[16 * NFULL + t]);
     }
-    if (!DIRECT && TG_GF_ON(16)) {
-      const int pad = token_pad(g);
-      uint8_t* const gbase = reinterpret_cast<uint8_t*>(ga.actions + g * blk) - pad;
-      const int total = pad + blk;
-      const int cfirst = (pad + 15) >> 4, cend = total >> 4;  // whole chunks [cfirst, cend) lie inside [pad, total)
-      if (cend > cfirst) copy_chunks(tbuf + 16 * cfirst, gbase + 16 * cfirst, cend - cfirst, t, nthr);
-      // the bytes in front of the first and behind the last whole chunk (none when the block is aligned)
-      const int head_end = 16 * cfirst < total ? 16 * cfirst : total;
-      if (pad + t < head_end) gbase[pad + t] = tbuf[pad + t];
-      const int tail0 = 16 * cend > head_end ? 16 * cend : head_end;
-      if (tail0 + t < total) gbase[tail0 + t] = tbuf[tail0 + t];
-    }
   };
 
   // Workgroup OR of a per-thread flag with ONE barrier (HIP's __syncthreads_or costs three): non-zero flags are OR-ed
   // into an LDS word (rare), barrier, everyone reads the word.  Four words used round-robin; a word is cleared by
   // thread 0 after the NEXT barrier (every reader has passed it by then) and needed again three barriers later.
-  uint32_t* const orw = reinterpret_cast<uint32_t*>(tokimg + 2 * tokbuf_bytes);
+  uint32_t* const orw = reinterpret_cast<uint32_t*>(img + G::IMG + 32);
   if (tid < 4) orw[tid] = 0;
   int orslot = 0;
   auto wg_or = [&](int v) {
@@ -455,60 +394,35 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
   };
 
   __syncthreads();  // T and the OR words are zero
-  TG_STAMP(1);
   int64_t prev = -1, cur = blockIdx.x;
   bool prev_exact = false;
-  int buf = 0;
-  int stamp = 2, stamp2 = 0;
-  (void)stamp;
-  (void)stamp2;
   while (true) {
     const bool has_cur = cur < ga.B;
-    TG_STAMP_LAST(stamp2++);  // last wavefront: loop top (B2 passed)
     // stores of the previous game: by everybody when nothing follows, else by the wavefronts that draw least
     if (prev >= 0) {
-      const uint8_t* const pbuf = tokimg + (buf ^ 1) * tokbuf_bytes;
-      if (!has_cur) store_outputs(prev, pbuf, !prev_exact, tid, NTHREADS);
-      else if (light) store_outputs(prev, pbuf, !prev_exact, light_tid, light_threads);
+      if (!has_cur) store_outputs(prev, !prev_exact, tid, NTHREADS);
+      else if (light) store_outputs(prev, !prev_exact, light_tid, light_threads);
     }
-    TG_STAMP(stamp++);  // stores of prev issued (thread 0 belongs to a drawing wavefront: ~ loop top)
-    TG_STAMP_LAST(stamp2++);  // last wavefront: its stores of prev are issued
     if (!has_cur) break;
-    uint8_t* const tbuf = tokimg + buf * tokbuf_bytes;
     int big = 0, bad = 0;  // big: factors beyond the byte products (exact fallback); bad: a token left int8 (flag)
-    draw(cur, DIRECT ? nullptr : tbuf + token_pad(cur), big, bad);
-    TG_STAMP(stamp++);  // own draw jobs done
-    TG_STAMP_LAST(stamp2++);
+    draw(cur, big, bad);
     const int verdict = wg_or((big ? 1 : 0) | ((bad & ~255) ? 2 : 0));  // B1: T, token image complete; image reads of prev done
-    TG_STAMP(stamp++);  // B1 passed
-    TG_STAMP_LAST(stamp2++);
     const bool exact = BASIS && (verdict & 1) != 0;  // workgroup-uniform; rare (drawn values are inside the byte products)
     int flag = 0;
     if (exact) {  // exact byte-wise form from the emitted tokens, straight to global memory
       note_fallback();
-      if constexpr (DIRECT) {  // the tokens are in global memory: every wavefront's stores must have landed first (vmcnt + barrier)
-        __syncthreads();
-        flag = exact_target_from_tokens<S, NTHREADS>(reinterpret_cast<const uint8_t*>(ga.actions + cur * blk), R, ga.shift,
-                                                     ga.target + cur * ga.out_stride);
-      } else {
-        flag = exact_target_from_tokens<S, NTHREADS>(tbuf + token_pad(cur), R, ga.shift, ga.target + cur * ga.out_stride);
-      }
+      __syncthreads();  // the tokens are in global memory: every wavefront's stores must have landed first (vmcnt + barrier)
+      flag = exact_target_from_tokens<S, NTHREADS>(reinterpret_cast<const uint8_t*>(ga.actions + cur * blk), R, ga.shift,
+                                                   ga.target + cur * ga.out_stride);
     } else {  // column tiles on the matrix cores -> the target image
       int hi = 0, lo = 0;
       if (TG_GF_ON(4)) accumulate_tiles<S, KS, NW, CHECK, LUT, (S % 4 != 0)>(T, img, Rp, tm, wave, col, h, hi, lo);
       flag = (hi > 127) | (lo < -128);
     }
-    TG_STAMP(stamp++);  // own tiles done
-    TG_STAMP_LAST(stamp2++);
     const bool any_ovf = (wg_or(flag) != 0) | ((verdict & 2) != 0);  // B2: the image is complete, T is free
-#ifndef TG_STAMPS
     if (tid == 0 && any_ovf && ga.overflow) ga.overflow[cur] = 1;
-#else
-    (void)any_ovf;
-#endif
     prev = cur;
     prev_exact = exact;
     cur += gridDim.x;
-    buf ^= 1;
   }
 }

@@ -2535,11 +2535,6 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
     //  (S=25), 24 / 35 / 41 / 45 / 55 at K = 8 / 16 / 20 / 24 / 32 (S=16), 58 / 82 / 106 against 88 / 96 / 99 at K = 12 / 24 / 32 (S=9))
     if (al && a.nact <= 256 && !no_mfma && (a.S == 9 || a.S == 16 || a.S == 25) && (pays || many_always)) {
       const int Rp = (a.nact + 31) & ~31;
-#ifdef TG_AB_SWITCHES
-#define TG_MANY_SET_ABLATE(a) ((a).only_flagged = getenv("TG_MANY_ABLATE") ? atoi(getenv("TG_MANY_ABLATE")) : 0)
-#else
-#define TG_MANY_SET_ABLATE(a) ((void)0)
-#endif
 #define TG_MANY_K(S_, KS_)                                                                       \
   do {                                                                                           \
     const int ldsb = many_mfma_lds_bytes<S_>(Rp);                                                \
@@ -2548,7 +2543,6 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
     const int64_t per_wg = (B + resident - 1) / resident;                                        \
     const int64_t grid = (B + per_wg - 1) / per_wg;                                              \
     (void)hipGetLastError();                                                                     \
-    TG_MANY_SET_ABLATE(a);                                                                       \
     hipLaunchKernelGGL((many_mfma_kernel<S_, KS_>), dim3((unsigned)grid), dim3(kBlock), ldsb, st, a, Rp); \
     a.only_flagged = 0;                                                                          \
     if (int rc = check_launch(fn)) return rc;                                                    \
@@ -2593,7 +2587,6 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       // 26 / 34 KB: 516 / 516 / 515 / 514 / 504 / 506 us)
       int s16_lds_pad = B * a.in_stride >= kNtLoadsToBytes ? 32000 : 0;  // (the kernel has no LDS of its own: 160 KB / 32 000 = 5)
 #ifdef TG_AB_SWITCHES
-      if (getenv("TG_S16_LDS_PAD")) s16_lds_pad = atoi(getenv("TG_S16_LDS_PAD"));
       if (TG_SWITCH("TG_S16_NO_DIGITS")) {  // the packed int16 form alone
         if (nt_band || TG_SWITCH("TG_S16_NT_LOADS"))
           hipLaunchKernelGGL((s16_step_kernel<MODE, true, true, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
@@ -2648,9 +2641,6 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       // 2 GiB of states, dynamic LDS 0 / 12 / 20 / 24 / 32 / 40 KB (7 / 6 / 5 / 4 / 3 / 3 per CU): 614 / 617 / 597 / 588 / 574 /
       // 572 us; two per CU: 751.  (BASELINE config 5's share, 61 MB: 15.0 / 15.1 / - / 16.1 / 16.1 -- there occupancy wins.)
       int s25_lds_pad = bytes25 >= kNtLoadsToBytes ? 36000 : 0;
-#ifdef TG_AB_SWITCHES
-      if (getenv("TG_S25_LDS_PAD")) s25_lds_pad = atoi(getenv("TG_S25_LDS_PAD"));
-#endif
       const bool nt_band = bytes25 >= kNtLoadsFromBytes && bytes25 < kNtLoadsToBytes;
       if ((nt_band || TG_SWITCH("TG_S25_NT_LOADS")) && !TG_SWITCH("TG_S25_NO_NT_LOADS"))
         hipLaunchKernelGGL((s25_step_kernel<true, true>), dim3((unsigned)B), dim3(kBlock), s25_lds_pad, st, a);
@@ -2718,16 +2708,9 @@ int tg_internal_gen_fused(int8_t* target, int8_t* actions, uint8_t* overflow, co
   ga.ablate = getenv("TG_GF_ABLATE") ? atoi(getenv("TG_GF_ABLATE")) : 0;
   wgs_override = getenv("TG_GF_WGS") ? atoi(getenv("TG_GF_WGS")) : 0;
 #endif
-#ifdef TG_AB_SWITCHES
-#define TG_GF_TOKIMG_VARIANT(S_, KS_, BAS_, CHK_) \
-  if (tokimg) kern = gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true, kLutShape, false>
-#else
-#define TG_GF_TOKIMG_VARIANT(S_, KS_, BAS_, CHK_) (void)0
-#endif
 #define TG_GF_K(S_, KS_, BAS_, CHK_)                                                               \
   do {                                                                                             \
-    const bool tokimg = TG_SWITCH("TG_GF_TOKIMG") && D.nthr == 2 && KS_ != 0;  /* (A/B library: the LDS token image) */ \
-    const int ldsb = genfused_lds_bytes<S_>(Rp, R, tokimg);                                        \
+    const int ldsb = genfused_lds_bytes<S_>(Rp);                                                   \
     static OccupancySlots occ;                                                                     \
     if (D.nthr == 2 && KS_ != 0) {  /* the reference's three values: the specialised draw evaluation */ \
       static OccupancySlots occ3, occ3l;                                                           \
@@ -2735,7 +2718,6 @@ int tg_internal_gen_fused(int8_t* target, int8_t* actions, uint8_t* overflow, co
       const bool lut = kLutShape && lut_values;                                                    \
       void (*kern)(GenArgs, int) = lut ? gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true, kLutShape>        \
                                        : gen_fused_kernel<S_, KS_, BAS_, 4, CHK_, true>;           \
-      TG_GF_TOKIMG_VARIANT(S_, KS_, BAS_, CHK_);                                                   \
       const int per_cu3 = wgs_override > 0 ? wgs_override : resident_per_cu(kern, ldsb, lut ? occ3l : occ3); \
       const int64_t resident3 = static_cast<int64_t>(per_cu3) * device_cu_count() * (wgs_override > 0 ? 1 : 2); \
       const int64_t per_wg3 = (B + resident3 - 1) / resident3;                                     \
@@ -2814,7 +2796,7 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
     return fail(TG_ERR_INVALID, "tg_step_i8: null pointer");
   tg::ApplyArgs a{state_in, state_out, actions, done, nullptr, nullptr, overflow, B,
                   game_stride_bytes, game_stride_bytes, S, 1, shift};
-  a.sweep = TG_SWITCH("TG_NO_SWEEP") ? 0 : static_cast<int>(g_sweep.fetch_add(1u, std::memory_order_relaxed) & 1u);
+  a.sweep = static_cast<int>(g_sweep.fetch_add(1u, std::memory_order_relaxed) & 1u);
   return launch_apply<tg::STEP>("tg_step_i8", a, static_cast<hipStream_t>(stream));
 }
 

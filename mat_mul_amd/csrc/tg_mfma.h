@@ -427,45 +427,11 @@ __device__ __forceinline__ uint32_t abs4_i8(uint32_t x) {
   return (x ^ (s1 * 0xFFu)) + s1;
 }
 
-// Diagnostic build only (-DTG_STAMPS, tools/stamp_many.py): workgroups 0, 64, .., 960 record the shader clock (s_memtime,
-// 2.4 GHz) at phase boundaries into the OVERFLOW buffer (32 uint64 per workgroup; B >= 4096), which this kernel never
-// writes otherwise; slot 0 = kernel entry, slot 1 = set-up done, slot 31 = s_memrealtime (100 MHz, one counter for the whole
-// chip) at exit.
-#ifdef TG_STAMPS
-// which workgroups record: 16 of them -- every 64th (one XCD, four CUs), or with -DTG_STAMPS_XCD the first of each XCD and
-// the 33rd (workgroup b runs on XCD b % 8)
-#ifdef TG_STAMPS_XCD
-#define TG_MSTAMP_SEL(b) ((b) < 8 ? (int)(b) : (((b) >= 256 + 0 && (b) < 256 + 8) ? (int)((b) - 256 + 8) : -1))
-#else
-#define TG_MSTAMP_SEL(b) ((((b) & 63) == 0 && ((b) >> 6) < 16) ? (int)((b) >> 6) : -1)
-#endif
-#define TG_MSTAMP(i)                                                                                        \
-  do {                                                                                                      \
-    const int tg_stamp_i = (i);                                                                             \
-    if (TG_MSTAMP_SEL(blockIdx.x) >= 0 && threadIdx.x == 0 && tg_stamp_i < 32 && a.overflow) \
-      reinterpret_cast<unsigned long long*>(a.overflow)[TG_MSTAMP_SEL(blockIdx.x) * 32 + tg_stamp_i] =              \
-          tg_stamp_i == 31 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define TG_MSTAMP(i) \
-  do {               \
-  } while (0)
-#endif
-
 template <int S, int KS>
 __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int Rp) {
   using G = MGeo<S>;
   static_assert((S % 8) < 3, "the two functional rows S, S+1 must be rows of the lower half-wave");
-#ifdef TG_AB_SWITCHES
-  const int ablate = a.only_flagged;  // A/B build only (TG_MANY_ABLATE, tools/ablate_many.py): 1 no token staging, 2 no state load,
-#define TG_MANY_ON(bit) (!(ablate & (bit)))  //  4 no action scalars, 8 no tiles, 16 no verdict scan, 32 no stores -- timing only
-#define TG_MANY_ABLATED (ablate != 0)        //  (an ablated run hands nothing over: the verdicts are meaningless)
-#else
-#define TG_MANY_ON(bit) true
-#define TG_MANY_ABLATED false
-#endif
   extern __shared__ __attribute__((aligned(16))) uint8_t mfma_smem[];
-  TG_MSTAMP(0);  // kernel entry
   if constexpr (KS != 0) Rp = 32 * KS;
   const int RS = Rp + 16;
   int8_t* const T = reinterpret_cast<int8_t*>(mfma_smem);
@@ -535,10 +501,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
 
   if (tid < 8) red[tid] = 0;
   int orpar = 0;
-  int stamp = 2;
-  (void)stamp;
   __syncthreads();
-  TG_MSTAMP(1);  // set-up done
   // A CU issues from its OLDEST workgroup first, so its four resident workgroups finish one after the other (11 us
   // apart at S=25, K=64) and the last one runs alone at the end.  A workgroup that is ahead steps back (s_setprio):
   // priority 3 while three or more games remain, 2 for the last but one, 1 for the first half of the last game, 0 for
@@ -554,7 +517,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
     // (the state is requested first: tokens and state then share ONE memory round trip)
     constexpr int NCP = (G::NCHUNK + kBlock - 1) / kBlock;  // image chunks per thread
     uint4 sq[NCP];
-    if (TG_MANY_ON(2)) {
+    {
       const int8_t* src = a.in + g * a.in_stride;
       if (G::TAIL != 0 && g == a.B - 1) {  // uniform: only the batch's last game may lack the bytes behind its tail
 #pragma unroll
@@ -571,7 +534,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       }
     }
     int big = 0;
-    if (srg < NRG && TG_MANY_ON(1)) {
+    if (srg < NRG) {
       for (int rb = 4 * srg; rb < Rp; rb += 4 * NRG * TB) {
         int f[TB][4];
 #pragma unroll
@@ -596,7 +559,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
         }
       }
     }
-    if (TG_MANY_ON(2)) {
+    {
 #pragma unroll
       for (int i = 0; i < NCP; ++i) {
         const int c = tid + kBlock * i;
@@ -607,10 +570,8 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
     // workgroup OR of `big` with ONE barrier (HIP's __syncthreads_or costs three): red[4 + parity] was cleared during
     // the previous game, is OR-ed here, read after the barrier; the other word is cleared for the next game
     if (big) atomicOr(reinterpret_cast<unsigned*>(&red[4 + orpar]), 1u);
-    TG_MSTAMP(stamp++);  // staged (own part)
     __syncthreads();
-    TG_MSTAMP(stamp++);  // B1 passed
-    const bool anybig = red[4 + orpar] != 0 && !TG_MANY_ABLATED;
+    const bool anybig = red[4 + orpar] != 0;
     if (tid == 0) red[4 + (orpar ^ 1)] = 0;
     orpar ^= 1;
     if (anybig) {  // factors beyond the byte products: the lattice kernels take this game
@@ -623,7 +584,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
     }
 
     // ---- 2a. per-action scalars: wavefront x < 3 takes factor vector x of every action ----
-    if (wave < 3 && TG_MANY_ON(4)) {
+    if (wave < 3) {
       const int uw = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: the weights come by scalar loads
       const int* wu0 = uw == 2 ? g_fw.w[0] : g_fw.uv[0][uw];
       const int* wu1 = uw == 2 ? g_fw.w[1] : g_fw.uv[1][uw];
@@ -650,7 +611,6 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
         smx[wave * Rp + r] = mx;
       }
     }
-    TG_MSTAMP(stamp++);  // scalars (own part)
     __syncthreads();
     // every wavefront: sum_r mu_r mv_r mw_r.  Above 127 the overflow bound cannot hold whatever the final state
     // is: hand the game over now, before the expensive part
@@ -662,8 +622,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       bound += static_cast<int>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_scan(static_cast<uint32_t>(pb))), 63));
       if (bound > (1 << 24)) bound = 1 << 24;
     }
-    const bool wide = bound > 127 && !TG_MANY_ABLATED;  // workgroup-uniform: the scalar bound cannot certify this game
-    TG_MSTAMP(stamp++);  // barrier + scalar bound
+    const bool wide = bound > 127;  // workgroup-uniform: the scalar bound cannot certify this game
     if (wide) {
       // ---- elementwise bound: Bnd = |X0| + sum_r |u_r| (x) |v_r| (x) |w_r|, the same tiles on absolute values ----
       for (int e = 16 * tid; e < G::TROWS * RS; e += 16 * kBlock) {
@@ -786,7 +745,6 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
 #pragma unroll
     for (int k = 0; k < TPW; k += 2) {
       if (G::NT % NW != 0 && wave + NW * k >= G::NT) break;
-      if (!TG_MANY_ON(8)) break;
       __builtin_amdgcn_sched_barrier(0);
       uint32_t XA[4], XB[4] = {0, 0, 0, 0};
       tile(k, XA);
@@ -838,9 +796,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
         if (mabs) atomicMax(&red[2], mabs);
       }
     }
-    TG_MSTAMP(stamp++);  // tiles (own part; elementwise pass included when wide)
     __syncthreads();  // image, action scalars and reductions complete
-    TG_MSTAMP(stamp++);  // B2 passed
 
     // ---- 3. verdict (every wavefront computes it: no further exchange) ----
     bool redo;
@@ -850,7 +806,7 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       const int maxfinal = red[2];
       uint32_t carry0 = 0, carry1 = 0;
       int first = -1;
-      for (int r0 = 0; r0 < Rp && TG_MANY_ON(16); r0 += 64) {
+      for (int r0 = 0; r0 < Rp; r0 += 64) {
         const int r = r0 + lane;
         uint32_t g0 = 0, g1 = 0;
         if (r < R) {
@@ -870,9 +826,8 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       redo |= first >= 0 && first < R - 1;                     // a candidate that the final state cannot confirm
       redo |= final_zero && first != R - 1;                    // cannot happen; never trust it silently
       dstep = (first == R - 1 && final_zero) ? R - 1 : -1;
-      if (TG_MANY_ABLATED) redo = false;
     }
-    if (!redo && TG_MANY_ON(32)) {
+    if (!redo) {
       int8_t* out = a.out + g * a.out_stride;
       for (int c = tid; c < G::NCHUNK; c += kBlock)
         store_chunk<G::TAIL>(out + 16 * c, *reinterpret_cast<const uint4*>(img + 16 * c), c == G::NCHUNK - 1);
@@ -881,9 +836,6 @@ __global__ __launch_bounds__(kBlock, 4) void many_mfma_kernel(ApplyArgs a, int R
       a.done_step[g] = redo ? kNeedsExact : dstep;
       if (redo) atomicAdd(&g_many_handovers, 1ull);
     }
-    TG_MSTAMP(stamp++);  // verdict + stores issued
     __syncthreads();
   }
-  TG_MSTAMP(stamp++);
-  TG_MSTAMP(31);
 }

@@ -108,7 +108,7 @@ def _run(script_text, tmp_path, marker, extra_env=None):
     assert res.returncode == 0 and marker in res.stdout, (res.stdout[-1000:], res.stderr[-3000:])
 
 
-@pytest.mark.parametrize("env_name", ["TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA", "TG_MFMA_MANY_ALWAYS", "TG_NO_FUSED_GEN", "TG_GF_NO_LUT", "TG_GF_TOKIMG"])
+@pytest.mark.parametrize("env_name", ["TG_NO_ROWS", "TG_NO_S16_DIRECT", "TG_NO_MFMA", "TG_MFMA_MANY_ALWAYS", "TG_NO_FUSED_GEN", "TG_GF_NO_LUT"])
 def test_ab_switch_paths_stay_exact(env_name, tmp_path):
     """The measurement switches (packed chunks instead of rows; vector ALU instead of the matrix cores) select
     kernels that the product dispatch no longer uses at these shapes -- they must stay bit-exact."""
@@ -118,7 +118,7 @@ def test_ab_switch_paths_stay_exact(env_name, tmp_path):
 @pytest.mark.parametrize("env_names", ["TG_S16_LINES", "TG_S16_NT_LOADS", "TG_S25_LINES", "TG_S25_NT_LOADS", "TG_NO_S25_DIRECT",
                                        "TG_NO_S16_DIRECT", "TG_NO_S9_DIRECT", "TG_S4_NT_LOADS", "TG_S4_NT_LOADS TG_S4_TOKEN_WAIT",
                                        "TG_TRACKED_SPARSE", "TG_TRACKED_FULL", "TG_S16_NO_DIGITS", "TG_S16_LINES TG_S16_NO_DIGITS", "TG_S16_NT_LOADS TG_S16_NO_DIGITS",
-                                       "TG_S4_NO_DIGITS", "TG_S4_NT_LOADS TG_S4_NO_DIGITS", "TG_S4_NT_LOADS TG_S4_TOKEN_WAIT TG_S4_NO_DIGITS", "TG_NO_SWEEP"])
+                                       "TG_S4_NO_DIGITS", "TG_S4_NT_LOADS TG_S4_NO_DIGITS", "TG_S4_NT_LOADS TG_S4_TOKEN_WAIT TG_S4_NO_DIGITS"])
 def test_single_step_variants_stay_exact(env_names, tmp_path):
     """The step variants the product takes by footprint only, forced here at small batches: S=16 / S=25 with whole-line
     stores (from 96 MiB of states on) and non-temporal state loads on top (320 MiB .. 1.5 GiB), S=4 with non-temporal
