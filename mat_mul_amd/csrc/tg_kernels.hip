@@ -2641,6 +2641,9 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       // 2 GiB of states, dynamic LDS 0 / 12 / 20 / 24 / 32 / 40 KB (7 / 6 / 5 / 4 / 3 / 3 per CU): 614 / 617 / 597 / 588 / 574 /
       // 572 us; two per CU: 751.  (BASELINE config 5's share, 61 MB: 15.0 / 15.1 / - / 16.1 / 16.1 -- there occupancy wins.)
       int s25_lds_pad = bytes25 >= kNtLoadsToBytes ? 36000 : 0;
+#ifdef TG_AB_SWITCHES
+      if (getenv("TG_S25_LDS_PAD")) s25_lds_pad = atoi(getenv("TG_S25_LDS_PAD"));  // (round 4: the occupancy study of the 2 GiB stream)
+#endif
       const bool nt_band = bytes25 >= kNtLoadsFromBytes && bytes25 < kNtLoadsToBytes;
       if ((nt_band || TG_SWITCH("TG_S25_NT_LOADS")) && !TG_SWITCH("TG_S25_NO_NT_LOADS"))
         hipLaunchKernelGGL((s25_step_kernel<true, true>), dim3((unsigned)B), dim3(kBlock), s25_lds_pad, st, a);
