@@ -162,6 +162,32 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
   const bool light = wave >= nheavy;
   const int light_tid = tid - 64 * nheavy, light_threads = NTHREADS - 64 * nheavy;
 
+  // S = 17 .. 31 (round 4): a vector's S token bytes leave as ONE 16-byte store per lane -- the lower lane half (elements
+  // 0..15 in Kv) its bytes 0..15, the upper half (elements 16..31) the LAST sixteen bytes S-16 .. S-1: its own S - 16 behind
+  // the 32 - S bytes in front of them, which it gets from its partner lane (v_permlane32_swap) and shifts into place
+  // (v_alignbyte_b32); the overlap is written twice with the same values.  Scattered stores are paid per INSTRUCTION (a
+  // lane's bytes lie 3 S bytes from its neighbour's: ~3 us of a 28 us launch per store instruction per job, round 3);
+  // this was 16 | 8 + 1 bytes = three instructions per job at S = 25.  Called by every lane (the exchange is cross-lane).
+  auto store_vector16 = [&](const uint32_t (&Kv)[4], int8_t* vec, bool on) {
+    constexpr int OFF = S > 16 ? S - 16 : 1, SH = OFF & 3, W0 = OFF >> 2;
+    uint32_t Lw[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int w = W0 + t;  // dword w of the vector's 32 bytes: lower half's K[w] for w < 4, the upper half's own K[w - 4]
+      if (w < 4) Lw[t] = __builtin_amdgcn_permlane32_swap(0u, Kv[w], false, false)[0];
+      else Lw[t] = Kv[(w - 4) & 3];
+    }
+    uint32_t Dq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t up = SH ? __builtin_amdgcn_alignbyte(Lw[d + 1], Lw[d], static_cast<uint32_t>(SH)) : Lw[d];
+      Dq[d] = h ? up : Kv[d];
+    }
+    int8_t* const pq = vec + (h ? OFF : 0);
+    const v4u_t q{Dq[0], Dq[1], Dq[2], Dq[3]};
+    if (on) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(pq), "v"(q) : "memory");
+  };
+
   // ---- draw (and transform) the factors of game g: registers -> T, the tokens -> global memory ----
   auto draw = [&](int64_t g, int& big, int& bad) {
     if (!TG_GF_ON(64)) return;  // (A/B build: no draw phase at all)
@@ -254,7 +280,10 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
             for (int k = KBOTH; k < KLOW; ++k) tcol[k * RS] = static_cast<int8_t>(static_cast<uint32_t>(F[k >> 2]) >> (8 * (k & 3)));
           }
         }
-        if (active && holds && TG_GF_ON(16)) {
+        if constexpr (!kSwap && S > 16) {
+          const uint32_t Kv[4] = {static_cast<uint32_t>(K[0]), static_cast<uint32_t>(K[1]), static_cast<uint32_t>(K[2]), static_cast<uint32_t>(K[3])};
+          store_vector16(Kv, ga.actions + g * blk + (3 * r + x) * S, active && TG_GF_ON(16));
+        } else if (active && holds && TG_GF_ON(16)) {
           // the vector's tokens: KLOW bytes (lane half 0) / KBOTH bytes (lane half 1) at (3 r + x) S + kbase of the game's
           // block, any alignment: whole dwords as unaligned global stores, then the tail bytes
           // As FEW store instructions and lane transactions as possible: these stores are scattered (a lane's bytes lie 3 S
@@ -298,7 +327,7 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
             // The tokens straight to global memory, in as few store instructions as the plain generator's (scattered stores
             // are paid per instruction): register group q holds the four consecutive rows 8 q + 4 h + (0..3); two
             // v_permlane32_swap hand the lower lane half rows 0..15 and the upper half rows 16..31 of the action's vector,
-            // which leave as 16 | 8 + 1 bytes at S = 25 (three instructions; a dword per group took four).
+            // which leave as one 16-byte store per lane at S = 25 (store_vector16; 16 | 8 + 1 bytes = three instructions in round 3).
             if (TG_GF_ON(16)) {
               uint32_t X[4];
 #pragma unroll
@@ -322,8 +351,12 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
                 if (nb - o >= 4) { reinterpret_cast<UnalignedU32*>(gp + o)->v = static_cast<uint32_t>(K[o >> 2]); o += 4; }
                 for (; o < nb; ++o) gp[o] = static_cast<int8_t>(static_cast<uint32_t>(K[o >> 2]) >> (8 * (o & 3)));
               };
-              if (h == 0) put(S < 16 ? S : 16);
-              else put(S - 16 < 0 ? 0 : (S - 16 < 16 ? S - 16 : 16));
+              if constexpr (S > 16) {  // one 16-byte store per lane (store_vector16)
+                const uint32_t Kv[4] = {static_cast<uint32_t>(K[0]), static_cast<uint32_t>(K[1]), static_cast<uint32_t>(K[2]), static_cast<uint32_t>(K[3])};
+                store_vector16(Kv, ga.actions + g * blk + (3 * r + x) * S, true);
+              } else if (h == 0) {
+                put(S < 16 ? S : 16);
+              }
             }
           }
 #pragma unroll

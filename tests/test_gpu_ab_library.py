@@ -217,8 +217,9 @@ for B, K in [(1, 3), (63, 5), (64, 9), (65, 17), (1000, 14), (4099, 25)]:
         want_lanes = "TG_STREAM_NO_LANES" not in __import__("os").environ
         n_units, gpu = ops.step_stream_layout(B, S, DEV)
         assert (gpu == 64) == want_lanes and n_units == -(-B // gpu)
-        for ready in (None, torch.ones(K, dtype=torch.int32, device=DEV)):
-            t = ops.alloc_states(B, S, DEV); t.copy_(dev(st))
+        for ready, pad in ((None, 16), (torch.ones(K, dtype=torch.int32, device=DEV), 16), (None, 48)):   # (48: a 96-byte game stride)
+            t = ops.alloc_states(B, S, DEV, pad_to=pad); t.copy_(dev(st))
+            assert B == 1 or t.stride(0) == (64 if pad == 16 else 96)
             ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
             prog = torch.zeros(n_units, dtype=torch.int32, device=DEV)
             status = torch.zeros(1, dtype=torch.int32, device=DEV)
