@@ -1013,6 +1013,38 @@ def fused_lines(dev, batches=(65536, 1 << 20)):
                      "us_expand_then_hash": round(two * 1e6, 2), "gain": round(two / fused, 3)})
         del kids, kd, kc, keys, tok, tgt
         torch.cuda.empty_cache()
+    # N1 at S=16: tg_step_emit is one kernel while its output stays below 128 MiB (1 024 games here), two launches inside the
+    # call beyond (8 192 games: the frames' write stream is the whole cost); beside it the step and the frames alone
+    for b2 in (1024, 8192):
+        s2, T = 16, 4
+        tok, tgt = ops.gen_demos(b2, s2, 2, dev, seed=6)
+        a0 = tok[:, 0].contiguous()
+        ring = ops.alloc_ring(b2, s2, T, dev)
+        for f in range(T):
+            ring[:, f].copy_(tgt)
+        dn = torch.zeros(b2, dtype=torch.uint8, device=dev)
+        sc = torch.empty((b2, 1), dtype=torch.float32, device=dev)
+        x = torch.empty((b2, T, s2, s2, s2), dtype=torch.float16, device=dev)
+        both = graph_time(lambda: ops.step_emit(ring, 0, a0, 1.0, torch.float16, out=x, scalars=sc, done=dn), dev, reps=10)
+        step_only = graph_time(lambda: ops.step(ring[:, 0], a0, out=ring[:, 1], done=dn), dev, reps=10)
+        emit_only = graph_time(lambda: ops.emit_frames(ring, 1, 1.0, torch.float16, out=x, scalars=sc), dev, reps=10)
+        nbytes = b2 * (s2 ** 3 * (T - 1) + 3 * s2 + s2 ** 3 + 1 + T * s2 ** 3 * 2 + 4)
+        pair = graph_time(lambda: (ops.step(ring[:, 0], a0, out=ring[:, 1], done=dn),
+                                   ops.emit_frames(ring, 1, 1.0, torch.float16, out=x, scalars=sc)), dev, reps=10)
+        ops.step_emit(ring, 0, a0, 1.0, torch.float16, out=x, scalars=sc, done=dn)
+        xf = x.clone()
+        ops.step(ring[:, 0], a0, out=ring[:, 1], done=dn)
+        x2, _ = ops.emit_frames(ring, 1, 1.0, torch.float16)
+        one_kernel = T * b2 * s2 ** 3 * 2 < (128 << 20)
+        also.append({"workload": f"N1 {'FUSED ' if one_kernel else ''}tg_step_emit: S={s2} batch={b2} T={T} float16 ("
+                                 f"{'one kernel' if one_kernel else 'two launches inside the call'}; "
+                                 f"{T * b2 * s2 ** 3 * 2 / 1e6:.0f} MB of output)",
+                     "ok": bool(torch.equal(xf, x2)), "us_per_launch": round(both * 1e6, 2), "us_step_alone": round(step_only * 1e6, 2),
+                     "us_emit_frames_alone": round(emit_only * 1e6, 2),
+                     "us_step_then_emit_frames": round(pair * 1e6, 2), "gain": round(pair / both, 3),
+                     "GBps": round(nbytes / both / 1e9, 1), "hbm_frac": round(nbytes / both / 1e9 / HBM_PEAK_GBS, 4)})
+        del x, ring, tok, tgt
+        torch.cuda.empty_cache()
     for b2 in batches:
         s2, T, k2 = 4, 4, 8
         reps = 20 if b2 <= 65536 else 5

@@ -231,8 +231,9 @@ int tg_emit_frames(const int8_t* ring, void* out, float* scalars, int out_dtype,
  * and get_scalars for fwd_infer, act.py:178-182).  The step reads ring slot head_slot and writes the new head into slot
  * (head_slot + 1) mod T (T = 1: in place); done / overflow as tg_step_i8; out[b][0] = float(new head), out[b][f] =
  * float(ring[b][(head_slot + 1 - f) mod T]); out_dtype, scalars, strides as tg_emit_frames.  The caller's head slot
- * afterwards is (head_slot + 1) mod T.  At S = 4 this is one kernel (the new head and the old head are emitted from
- * registers); other sizes run tg_step_i8 and tg_emit_frames inside the call. */
+ * afterwards is (head_slot + 1) mod T.  At S = 4 and S = 16 this is one kernel while the output (< 128 MiB) stays in the
+ * caches (the new head and the old head are emitted from registers); other sizes, layouts and larger outputs run
+ * tg_step_i8 and tg_emit_frames inside the call. */
 int tg_step_emit(int8_t* ring, const int8_t* actions, void* out, float* scalars, uint8_t* done, uint8_t* overflow,
                  int out_dtype, int64_t B, int S, int T, int head_slot, float t_step, int64_t frame_stride_bytes,
                  int64_t game_stride_bytes, int shift, tg_stream_t stream);

@@ -1608,6 +1608,108 @@ __global__ __launch_bounds__(kBlock, LINES ? 6 : 8) void s16_step_kernel(ApplyAr
 }
 
 // =============================================================================================
+// tg_step_emit at S = 16 (round 4): one env step on the history ring AND the (B,T,16,16,16) float model input of the new
+// state in one launch, while that output stays in the caches (two launches -- tg_step_i8, then emit_frames_kernel --
+// measured 15.9 us at 1 024 games, T = 4, float16, of which the frames alone are 9.0: the step's round trip and a launch
+// boundary are what a fused kernel saves; from kStreamOutBytes of output on the frames kernel's write stream is the
+// whole cost and the entry stays two launches).
+// s16_step_kernel's mapping -- a wavefront per game, lane (r, j) owns rows (i = r + 4 n, j) = chunks lane + 64 n -- so a
+// lane's sixteen elements of a chunk leave as 32 (16-bit types) or 64 (float32) contiguous output bytes; frame 0 comes
+// from the registers that hold the new head, frame 1 from the registers the step read the old head into, older frames
+// from the ring.
+// =============================================================================================
+template <typename OutT, bool NT>
+__device__ __forceinline__ void s16_emit_chunk(OutT* dst, const uint4& q) {  // sixteen int8 -> sixteen OutT at dst
+  const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+  if constexpr (sizeof(OutT) == 4) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) s4_emit_f32<NT>(reinterpret_cast<float*>(dst) + 4 * d, w[d]);
+  } else {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const uint2 a = s4_cvt16<OutT>(w[2 * hh]), b = s4_cvt16<OutT>(w[2 * hh + 1]);
+      const uint4 o{a.x, a.y, b.x, b.y};
+      if constexpr (NT) store16_nt(dst + 8 * hh, o);
+      else *reinterpret_cast<uint4*>(dst + 8 * hh) = o;
+    }
+  }
+}
+
+template <typename OutT, bool NT>
+__global__ __launch_bounds__(kBlock) void s16_step_emit_kernel(StepEmitArgs a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  int64_t g = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave;
+  const bool live = g < a.B;
+  if (!live) g = a.B - 1;
+  const int8_t* tok = a.actions + g * 48;
+  int8_t* const game = a.ring + g * a.game_stride;
+  const int nxt = a.head + 1 < a.T ? a.head + 1 : 0;
+  const int8_t* src = game + a.head * a.frame_stride + 16 * lane;
+  const uint4 p0 = *reinterpret_cast<const uint4*>(src), p1 = *reinterpret_cast<const uint4*>(src + 1024),
+              p2 = *reinterpret_cast<const uint4*>(src + 2048), p3 = *reinterpret_cast<const uint4*>(src + 3072);
+  const uint4 uq = *reinterpret_cast<const uint4*>(tok);
+  const uint4 vq = *reinterpret_cast<const uint4*>(tok + 16);
+  const uint4 wq = *reinterpret_cast<const uint4*>(tok + 32);
+  auto wfetch = [&]() { return *reinterpret_cast<const uint4*>(tok + 32); };
+  const int vj = tok[16 + (lane & 15)] - a.shift;
+  const int r = lane >> 4;
+  uint32_t nz = 0, ovf = 0;
+  const uint32_t shp = (static_cast<uint32_t>(a.shift) & 0xFFFFu) | (static_cast<uint32_t>(a.shift) << 16);
+  const bool wide_shift = static_cast<unsigned>(a.shift + 127) > 254u;
+  const uint32_t tok_or = uq.x | uq.y | uq.z | uq.w | vq.x | vq.y | vq.z | vq.w | wq.x | wq.y | wq.z | wq.w;
+  const int dig_limit = (tok_or & 0xFCFCFCFCu) == 0 ? s4_digits_limit(a.shift) : -1;
+  const uint32_t shrep = static_cast<uint32_t>(a.shift) * 0x01010101u;
+  const uint32_t Wd[4] = {wq.x - shrep, wq.y - shrep, wq.z - shrep, wq.w - shrep};
+  auto chunk = [&](const uint4& x, int uvn, uint32_t& cnz) {  // (s16_step_kernel: the digit form first, then the packed int16 form)
+    uint4 res;
+    if (__builtin_expect(s16_chunk_digits(x, uvn, Wd, dig_limit, res, cnz), 1)) return res;
+    uint32_t wp[8];
+    unpack_pairs(wq, wp);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) wp[p] = pk_sub_i16(wp[p], shp);
+    return s16_chunk(x, uvn, wp, wfetch, a.shift, wide_shift, cnz, ovf);
+  };
+  OutT* const out = static_cast<OutT*>(a.out) + g * (static_cast<int64_t>(a.T) * 4096) + 16 * lane;
+  int8_t* const dst = game + nxt * a.frame_stride + 16 * lane;
+  auto one = [&](int n, const uint4& pn, uint32_t udw) {
+    const int ui = a.shift - __builtin_amdgcn_sbfe(static_cast<int>(udw), 8 * r, 8);  // -(u_i), i = r + 4 n
+    uint32_t cnz;
+    const uint4 res = chunk(pn, ui * vj, cnz);
+    nz |= cnz;
+    if (live) {
+      *reinterpret_cast<uint4*>(dst + 1024 * n) = res;                      // the new head -> ring slot nxt
+      s16_emit_chunk<OutT, NT>(out + 1024 * n, res);                        // frame 0
+      if (a.T > 1) s16_emit_chunk<OutT, NT>(out + 4096 + 1024 * n, pn);     // frame 1: the old head
+    }
+  };
+  one(0, p0, uq.x);
+  one(1, p1, uq.y);
+  one(2, p2, uq.z);
+  one(3, p3, uq.w);
+  if (live) {
+    int slot = a.head;
+    for (int f = 2; f < a.T; ++f) {  // older frames from the ring
+      slot = slot > 0 ? slot - 1 : a.T - 1;
+      const int8_t* const old = game + slot * a.frame_stride + 16 * lane;
+      const uint4 z0 = *reinterpret_cast<const uint4*>(old), z1 = *reinterpret_cast<const uint4*>(old + 1024),
+                  z2 = *reinterpret_cast<const uint4*>(old + 2048), z3 = *reinterpret_cast<const uint4*>(old + 3072);
+      OutT* const of = out + static_cast<int64_t>(f) * 4096;
+      s16_emit_chunk<OutT, NT>(of, z0);
+      s16_emit_chunk<OutT, NT>(of + 1024, z1);
+      s16_emit_chunk<OutT, NT>(of + 2048, z2);
+      s16_emit_chunk<OutT, NT>(of + 3072, z3);
+    }
+  }
+  const bool any_nz0 = __ballot(nz != 0) != 0;
+  const bool any_ovf0 = __ballot(ovf != 0) != 0;
+  if (lane == 0 && live) {
+    a.done[g] = any_nz0 ? 0 : 1;
+    if (a.scalars) a.scalars[g] = a.t_step;
+    if (a.overflow && any_ovf0) a.overflow[g] = 1;
+  }
+}
+
+// =============================================================================================
 // tg_step_tracked_i8 at S = 16 (round 3; s25_tracked_kernel in tg_packed.h has the argument): the in-place step that
 // loads only the rows the action touches -- row (i, j) changes iff u_i v_j != 0, which the tokens alone decide: ~9 % of the
 // rows, in ~28 % of the game's 128-byte lines -- with the number of non-zero entries carried per game.
@@ -3080,6 +3182,28 @@ int tg_step_emit(int8_t* ring, const int8_t* actions, void* out, float* scalars,
     else if (out_dtype == 2) TG_SE(__hip_bfloat16);
     else TG_SE(float);
 #undef TG_SE
+    return check_launch(fn);
+  }
+  // S = 16 while the output stays in the caches: one launch (s16_step_emit_kernel)
+  const int64_t out_bytes16 = B * T * 4096 * (out_dtype ? 2 : 4);
+  const bool fused16 = S == 16 && aligned16(ring) && frame_stride_bytes % 16 == 0 && game_stride_bytes % 16 == 0 && aligned16(actions) &&
+                       (out_bytes16 < tg::kStreamOutBytes || TG_SWITCH("TG_STEP_EMIT_FUSED")) && !TG_SWITCH("TG_STEP_EMIT_UNFUSED");
+  if (fused16) {
+    tg::StepEmitArgs a{ring, actions, out, scalars, done, overflow, B, frame_stride_bytes, game_stride_bytes, T, head_slot, shift, t_step};
+    const int64_t blocks = (B + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
+    const bool nt = out_bytes16 >= tg::kStreamOutBytes;
+    const dim3 grid(static_cast<unsigned>(blocks)), block(tg::kBlock);
+    (void)hipGetLastError();
+#define TG_SE16(OutT_)                                                                             \
+  do {                                                                                             \
+    if (nt) hipLaunchKernelGGL((tg::s16_step_emit_kernel<OutT_, true>), grid, block, 0, st, a);   \
+    else hipLaunchKernelGGL((tg::s16_step_emit_kernel<OutT_, false>), grid, block, 0, st, a);     \
+  } while (0)
+    if (out_dtype == 1) TG_SE16(__half);
+    else if (out_dtype == 2) TG_SE16(__hip_bfloat16);
+    else TG_SE16(float);
+#undef TG_SE16
     return check_launch(fn);
   }
   // other sizes and layouts: the step into the next ring slot, then the frames (two launches inside this call)

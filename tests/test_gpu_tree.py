@@ -191,6 +191,47 @@ def test_step_emit_random_against_oracle():
     assert np.array_equal(host(x[:, 0]).astype(np.int8), new) and bool((buf[:32] == 99).all()) and bool((buf[-32:] == 99).all())
 
 
+@pytest.mark.parametrize("B,T", [(1, 1), (5, 2), (131, 4), (66, 3)])
+def test_step_emit_fused_at_s16(B, T):
+    """Round 4: at S=16 tg_step_emit is ONE kernel while the output stays in the caches (s16_step_emit_kernel): every head
+    slot of the ring, float32 / float16 / bfloat16, ragged batches (the last workgroup's dead wavefronts), wide factors (the
+    32-bit redo, overflow), terminal games, guard elements around the output -- ring, model input, done, overflow and
+    scalars against the oracle, and equal to the two-launch path (step, then emit_frames)."""
+    S = 16
+    rng = np.random.default_rng(B * 10 + T)
+    frames = rng.integers(-3, 4, size=(B, T, S, S, S)).astype(np.int8)
+    ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, 3 * S)).astype(np.int8)
+    ac[::4] = rng.integers(-60, 60, size=ac[::4].shape)
+    for head in range(T):
+        if B > 2:
+            frames[2, head] = O.action_to_tensor(ac[2:3])[0].astype(np.int8)     # game 2 is done after the step
+        new, want_done, want_ovf = O.step_i8(frames[:, head], ac)
+        want = frames.copy()
+        want[:, (head + 1) % T] = new
+        order = [((head + 1) % T - f) % T for f in range(T)]
+        for dt in (torch.float32, torch.float16, torch.bfloat16):
+            ring = ops.alloc_ring(B, S, T, DEV)
+            ring.copy_(dev(frames))
+            ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+            n = B * T * S ** 3
+            buf = torch.full((n + 128,), 99.0, dtype=dt, device=DEV)
+            x = buf[64:64 + n].view(B, T, S, S, S)
+            x, sc, done, nxt = ops.step_emit(ring, head, dev(ac), 3.0, dtype=dt, out=x, overflow=ovf)
+            assert nxt == (head + 1) % T and np.array_equal(host(ring), want), (B, T, head, dt)
+            assert np.array_equal(x.float().cpu().numpy(), want[:, order].astype(np.float32)), (B, T, head, dt)
+            assert np.array_equal(host(done), want_done) and np.array_equal(host(ovf), want_ovf) and bool((sc == 3.0).all())
+            assert bool((buf[:64] == 99).all()) and bool((buf[-64:] == 99).all())
+            # the two-launch path on the same inputs
+            ring2 = ops.alloc_ring(B, S, T, DEV)
+            ring2.copy_(dev(frames))
+            d2 = torch.zeros(B, dtype=torch.uint8, device=DEV)
+            ops.step(ring2[:, head], dev(ac), out=ring2[:, (head + 1) % T], done=d2)
+            x2, sc2 = ops.emit_frames(ring2, (head + 1) % T, 3.0, dtype=dt)
+            assert torch.equal(x, x2) and torch.equal(ring, ring2) and torch.equal(done, d2)
+    if B > 2:
+        assert want_done[2] == 1
+
+
 def test_functional_expand_new_candidates_batched():
     """The reference-named wrapper over a BATCH of leaves against the oracle's per-leaf filter sharing one tree."""
     from mat_mul_amd import functional as F
