@@ -271,27 +271,17 @@ __global__ __launch_bounds__(64 * NW) void gen_fused_kernel(GenArgs ga, int Rp) 
         // elements k < KBOTH are valid in both lane halves (kbase 0 and 16), KBOTH <= k < KLOW only for kbase == 0:
         // two straight runs of byte writes instead of sixteen individually predicated ones
         constexpr int KBOTH = kSwap ? 0 : (S - 16 < 16 ? S - 16 : 16), KLOW = S < 16 ? S : 16;
-        if (TG_GF_ON(2)) {
-          // (round 4) T[row][r] is written as DWORDS.  A lane holds the bytes of ITS action for sixteen rows; sixteen
-          // ds_write_b8 per lane put four lanes' bytes into every dword they touch (3.7 of 29.8 us by ablation, 71 % of the
-          // kernel's LDS-active cycles were bank conflicts).  The four lanes of a quad transpose their 4 x 4 bytes (rows x
-          // actions) per dword -- two DPP exchanges and two v_perm_b32 -- and lane j writes row 4 q + j for the quad's four
-          // actions: four aligned ds_write_b32 instead of sixteen byte writes and their shifts.  Inactive actions (r >= R)
-          // hold zeros, which is what their cells of T hold anyway.
-          const int j4 = lane & 3;
-          const uint32_t sel1 = (j4 & 1) ? 0x03070105u : 0x06020400u, sel2 = (j4 & 2) ? 0x03020706u : 0x05040100u;
-          const unsigned long long am = __ballot(active && holds);
-          const bool qact = ((am >> (lane & ~3)) & 0xFull) != 0;  // some action of this lane's quad is live
-          const int nrows = kbase == 0 ? KLOW : KBOTH;             // rows this lane half holds
-          int8_t* const tq = T + (x * S + kbase + j4) * RS + (r & ~3);
+        if (active && holds && TG_GF_ON(2)) {
+          // (round 4, tried and taken out again: the four lanes of a quad transposing their 4 x 4 bytes -- two DPP exchanges, two
+          // v_perm_b32 per dword -- so that T is written as four aligned dwords instead of sixteen bytes: bit-exact, LDS
+          // instructions -15 %, SQ_WAIT_INST_LDS -40 %, but +66 VALU per game and wavefront, SQ_LDS_BANK_CONFLICT unchanged
+          // (the conflicts are not these writes) and 25.29 against 25.18 us.)
+          int8_t* const tcol = T + (x * S + kbase) * RS + r;
 #pragma unroll
-          for (int q = 0; q < (KLOW + 3) / 4; ++q) {
-            const uint32_t X = static_cast<uint32_t>(F[q]);
-            const uint32_t P = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(X), 0xB1, 0xf, 0xf, false));  // lane ^ 1
-            const uint32_t A = __builtin_amdgcn_perm(P, X, sel1);
-            const uint32_t Q = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(A), 0x4E, 0xf, 0xf, false));  // lane ^ 2
-            const uint32_t Y = __builtin_amdgcn_perm(Q, A, sel2);
-            if (qact && holds && 4 * q + j4 < nrows) *reinterpret_cast<uint32_t*>(tq + 4 * q * RS) = Y;
+          for (int k = 0; k < KBOTH; ++k) tcol[k * RS] = static_cast<int8_t>(static_cast<uint32_t>(F[k >> 2]) >> (8 * (k & 3)));
+          if (kbase == 0) {
+#pragma unroll
+            for (int k = KBOTH; k < KLOW; ++k) tcol[k * RS] = static_cast<int8_t>(static_cast<uint32_t>(F[k >> 2]) >> (8 * (k & 3)));
           }
         }
         if constexpr (!kSwap && S > 16) {

@@ -59,6 +59,9 @@ for name in ("bench_driver", "bench_graph", "bench_graph_S16", "bench_eager", "b
     j = src / f"{name}.json"
     if j.exists() and j.stat().st_size:
         shutil.copy(j, dst / f"{tag}_{name}.json")
+for extra, name in (("bench_also_driver_cmd.json", "bench_also_driver_cmd.json"), ("fused_n1_n2.jsonl", "fused_n1_n2.jsonl")):
+    if (src / extra).exists():
+        shutil.copy(src / extra, dst / f"{tag}_{name}")
 lf = src / "launch_floor.txt"
 if lf.exists():
     shutil.copy(lf, dst / f"{tag}_launch_floor.txt")
@@ -66,7 +69,8 @@ if (src / "share_floor.txt").exists():
     shutil.copy(src / "share_floor.txt", dst / f"{tag}_share_floor.txt")
 for probe, name in (("read_bw_probe", "read_bandwidth"), ("issue_rate_probe", "issue_rates"), ("shader_clock_probe", "shader_clock"),
                     ("expand_probe", "expand_probe"), ("aux_ops", "aux_ops"), ("generator_series", "generator_series"),
-                    ("step_series", "step_series"), ("stride_ab", "stride_ab"), ("expand25_probe", "expand25_probe")):
+                    ("step_series", "step_series"), ("stride_ab", "stride_ab"), ("expand25_probe", "expand25_probe"),
+                    ("stream_share", "stream_share"), ("stream_small", "stream_small")):
     if (src / f"{probe}.txt").exists():
         shutil.copy(src / f"{probe}.txt", dst / f"{tag}_{name}.txt")
 

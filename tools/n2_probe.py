@@ -1,5 +1,5 @@
 import sys, json, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 dev = torch.device('cuda:0')
 for a in bench.fused_lines(dev, batches=()):

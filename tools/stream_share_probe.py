@@ -1,7 +1,7 @@
 """tg_step_stream_i8 at S=4: per-step time with ready words (pre-set) against no ready words, with and without progress.
 VERDICT r3 item 2c: 6.14 ps per game-step at 131 072 games (resident, ready + progress) against 4.98 at 2^20 in rounds."""
 import statistics, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from mat_mul_amd import ops
 dev = torch.device('cuda:0')
 

@@ -1,7 +1,7 @@
 """How long does a producer on a second stream need until its first release is visible to a resident stepper?
 (The stepper's bounded wait must cover it: round 4 found stream creation + first launch on a new queue take > 1 s.)"""
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from mat_mul_amd import ops
 DEV = 'cuda:0'
 for trial in range(3):
