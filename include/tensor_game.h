@@ -114,7 +114,7 @@ int tg_step_many_i8(const int8_t* state_in, int8_t* state_out, const int8_t* act
  * No wavefront ever waits for another one, so the launch itself cannot deadlock; a producer that waits for the WHOLE
  * batch before releasing the next step additionally needs every unit resident at once: at S = 4
  * tg_step_stream_layout chooses the games per wavefront so that this holds and refuses batches beyond what the
- * device keeps resident (about 4.5e5 games on the 256 CUs of an MI355X; with ready == NULL tg_step_stream_i8 takes any B: units
+ * device keeps resident (262 144 games on the 256 CUs of an MI355X: four wavefronts of 64 games per SIMD; with ready == NULL tg_step_stream_i8 takes any B: units
  * of 64 games run in rounds, progress -- if given -- has (B + 63) / 64 words); S = 16 (one wavefront per game, the 4 KiB of
  * a game in registers) holds 32 games per CU = 8 192 on 256 CUs; S = 25 (one wavefront per game, the game's 15 625
  * bytes in registers) holds 16 games per CU = 4 096 on 256 CUs.  Beyond these (tg_step_stream_capacity) S = 16 / 25 run

@@ -1039,7 +1039,8 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
   // the loads behind them" is exactly the previous block's stores; hipcc's own bookkeeping would drain everything,
   // progress store included, at the loop header.  No asm load is in flight across the loop's back edge.
   // One dword per lane and step (lane q holds dword min(q, 2) of its game's twelve bytes; s4_team_token_bcast).
-  constexpr int D = NG == 1 ? 8 : (NG == 2 ? 4 : 2);
+  static_assert(NG == 1 || NG == 2, "NG = 4 / 8 were retired with the one-game-per-lane kernel");
+  constexpr int D = NG == 1 ? 8 : 4;
   uint32_t tk[D][NG], pollv = 0u;
   const uint32_t toff0 = static_cast<uint32_t>(g0 + lg) * 12u + 4u * static_cast<uint32_t>(q < 3 ? q : 2);
   const uint32_t toff_last = static_cast<uint32_t>(a.B - 1) * 12u + 4u * static_cast<uint32_t>(q < 3 ? q : 2);
@@ -1146,9 +1147,6 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
         if (live[n] && q == 0)  // write-through (sc1) stores: visible to other agents once this wavefront's vmcnt drains
           __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(team_l1 == 0 ? 1 : 0), drs,
                                                static_cast<int>(static_cast<int64_t>(k) * a.B + g[n]), 0, 16);
-        // one game at a time: left alone hipcc interleaves the NG games of a step (nothing convergent separates them any
-        // more) and NG = 4 / 8 need 103 / 196 VGPRs instead of 72 / 128 -- half the resident batch
-        if constexpr (NG > 1) __builtin_amdgcn_sched_barrier(0);
       }
     };
 #pragma unroll
@@ -2908,20 +2906,18 @@ int tg_step_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions,
 constexpr uint32_t kStreamWaitTicks = 100000000u;  // 1.0 s of s_memrealtime (100 MHz)
 
 // Units of each streamed-stepper variant this device keeps resident at once (from the occupancy of ITS kernel on THIS device).
-// S = 4: NG games x 16 per wavefront (NG = 1, 2 run 8 workgroups per CU, NG = 4 / 8 fewer), or 64 games per wavefront in the
+// S = 4: NG games x 16 per wavefront (NG = 1, 2: 8 workgroups per CU), or 64 games per wavefront in the
 // one-game-per-lane kernel (kStreamLanes; four workgroups per CU at 122 VGPRs).
 constexpr int kStreamLanes = 0;
 static int64_t stream_units_resident(int S, int ng) {
-  static OccupancySlots occ1, occ2, occ4, occ8, occ16, occ25, occl;
+  static OccupancySlots occ1, occ2, occ16, occ25, occl;
   const int64_t cus = device_cu_count();
   if (S == 16) return cus * 4 * resident_per_cu(tg::s16_stream_kernel, 0, occ16);
   if (S == 25) return cus * 4 * resident_per_cu(tg::s25_stream_kernel, 0, occ25);
   switch (ng) {
     case kStreamLanes: return cus * 4 * resident_per_cu(tg::s4_stream_kernel_lanes, 0, occl);
     case 1: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<1>, 0, occ1);
-    case 2: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<2>, 0, occ2);
-    case 4: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<4>, 0, occ4);
-    default: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<8>, 0, occ8);
+    default: return cus * 4 * resident_per_cu(tg::s4_stream_kernel<2>, 0, occ2);
   }
 }
 
@@ -2940,7 +2936,7 @@ static int s4_stream_variant(int64_t B, int64_t* units, int* games_per_unit, int
     *units = (B + 63) / 64, *games_per_unit = 64;
     return kStreamLanes;
   }
-  for (int ng = 1; ng <= 8; ng *= 2) {
+  for (int ng = 1; ng <= 2; ng *= 2) {  // (NG = 4 / 8 -- 103 / 196 VGPRs, no more resident games than the lane kernel -- went in round 4)
     const int64_t u = (B + 16 * ng - 1) / (16 * ng), cap = stream_units_resident(4, ng);
     if (u <= cap) {
       *units = u, *games_per_unit = 16 * ng;
@@ -2960,7 +2956,7 @@ int tg_step_stream_capacity(int S, int64_t* games) {
   int64_t most = 0;
   if (S == 4) {
     most = stream_units_resident(4, kStreamLanes) * 64;
-    for (int ng = 1; ng <= 8; ng *= 2) {
+    for (int ng = 1; ng <= 2; ng *= 2) {
       const int64_t c = stream_units_resident(4, ng) * 16 * ng;
       most = c > most ? c : most;
     }
@@ -3046,9 +3042,7 @@ int tg_step_stream_i8(int8_t* state, const int8_t* actions, uint8_t* done, uint8
   switch (variant) {
     case kStreamLanes: hipLaunchKernelGGL(tg::s4_stream_kernel_lanes, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
     case 1: hipLaunchKernelGGL(tg::s4_stream_kernel<1>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(tg::s4_stream_kernel<2>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(tg::s4_stream_kernel<4>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
-    default: hipLaunchKernelGGL(tg::s4_stream_kernel<8>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
+    default: hipLaunchKernelGGL(tg::s4_stream_kernel<2>, dim3(grid), dim3(tg::kBlock), 0, st, a); break;
   }
   return check_launch(fn);
 }

@@ -132,4 +132,4 @@ def test_resident_steppers_never_touch_a_register_before_its_load_is_waited_for(
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     names, problems = mod.audit(mod.assembly())
-    assert len(names) == 6 and not problems, problems   # s4 x 4, s4 one-game-per-lane, s16
+    assert len(names) == 4 and not problems, problems   # s4 x 2, s4 one-game-per-lane, s16

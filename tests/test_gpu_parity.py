@@ -1599,10 +1599,8 @@ def test_step_stream_layout_never_exceeds_what_the_device_keeps_resident():
             assert "resident" in str(e) and B > 131072 and B > cap
             continue
         assert B <= cap
-        assert gpu in (16, 32, 64, 128) and units == -(-B // gpu)
+        assert gpu in (16, 32, 64) and units == -(-B // gpu)
         assert units <= cus * 32                                          # never more than 8 wavefronts per SIMD
-        if gpu == 128:
-            assert units <= cus * 24
         if 57344 <= B <= 262144:
             assert gpu == 64 and units <= cus * 16                        # the lane kernel: four wavefronts per SIMD
         if B < 57344:
