@@ -753,6 +753,32 @@ def test_full_size_generate_replay_terminate(S, B, R):
     assert not bool(state.any())
 
 
+@pytest.mark.parametrize("S,B,R", [(25, 88000, 3),       # 1.28 GiB of S=25 states: three workgroups per CU (unused dynamic LDS), plain loads
+                                   (16, 336000, 3),      # 1.28 GiB of S=16 states: whole lines, five workgroups per CU
+                                   (4, 6300000, 3)])     # 385 MiB of S=4 states: non-temporal loads + the token awaited first
+def test_launch_shapes_beyond_the_caches_replay_to_zero(S, B, R):
+    """the launch shapes tg_step_i8 takes only by FOOTPRINT (occupancy held down by unused dynamic LDS from 1.25 GiB
+    on, the S=4 token wait from 384 MiB) had their arithmetic variants forced against the oracle at small batches, but the
+    launches themselves ran at full size only under bench.py's self-check.  Here: generate, replay the demonstration's own
+    actions in reverse with the plain step (and with the tracked one the env takes by itself) -- every game must be all
+    zero exactly at the last step, twice (both sweep directions), and step_many must agree."""
+    demos = SyntheticDemos(R, B, 1, S, DEV, seed=S + 1)
+    rev = demos.action_seq.flip(1).contiguous()
+    for track in (False, None):
+        env = TensorGameEnv(B, S, DEV, track_nnz=track)
+        for _ in range(2):
+            env.reset(demos.target_tensor)
+            for k in range(R):
+                state, done = env.step(rev[:, k])
+                if k < R - 1:
+                    assert not bool(done.all())
+            assert bool(done.all()) and not bool(state.any()) and not env.any_overflow()
+        del env
+        torch.cuda.empty_cache()
+    final, done_step = ops.step_many(demos.target_tensor, demos.action_seq)
+    assert not bool(final.any()) and int(done_step.max()) == R - 1 and int(done_step.min()) >= 0
+
+
 def test_sharded_env_equals_single_env():
     S, B, R = 4, 1000, 7
     demos = SyntheticDemos(R, B, 1, S, DEV, seed=4)
