@@ -102,6 +102,25 @@ for c in range(cases):
         ok = ok and np.array_equal(kids.cpu().numpy(), wk) and np.array_equal(d.cpu().numpy(), wd)
         ok = ok and np.array_equal(ch.cpu().numpy(), wc) and np.array_equal(ovk.cpu().numpy(), wo)
         ok = ok and np.array_equal(t.cpu().numpy(), st)
+    # round 4: keys formed inside the expansion (S = 4, 16) and step + model input in one kernel (S = 4, 16), same material
+    if S in (4, 16) and abs(shift) <= 127:
+        kids, d, ch, keys = ops.expand(padded(st), torch.from_numpy(ak).to(DEV), shift=shift, want_keys=True)
+        ok = ok and np.array_equal(kids.cpu().numpy(), wk)
+        ok = ok and np.array_equal(keys.cpu().numpy().view(np.uint64), O.state_hash(wk.reshape(B * k, S, S, S)).reshape(B, k))
+        T = int(rng.integers(1, 5))
+        frames = rng.integers(-3, 4, size=(B, T, S, S, S)).astype(np.int8)
+        head = int(rng.integers(T))
+        frames[:, head] = st
+        ring = ops.alloc_ring(B, S, T, DEV)
+        ring.copy_(torch.from_numpy(frames).to(DEV))
+        ovf = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        dt = [torch.float32, torch.float16, torch.bfloat16][c % 3]
+        x, sc, dn, nxt = ops.step_emit(ring, head, torch.from_numpy(tok).to(DEV), 2.0, dtype=dt, overflow=ovf, shift=shift)
+        wantr = frames.copy()
+        wantr[:, (head + 1) % T] = want
+        order = [((head + 1) % T - f) % T for f in range(T)]
+        ok = ok and np.array_equal(ring.cpu().numpy(), wantr) and np.array_equal(x.float().cpu().numpy(), wantr[:, order].astype(np.float32))
+        ok = ok and np.array_equal(dn.cpu().numpy(), wdone) and np.array_equal(ovf.cpu().numpy(), wovf)
     if not ok:
         bad += 1
         print("MISMATCH", dict(case=c, S=S, B=B, shift=shift, dens=dens, kind=kind), flush=True)
