@@ -941,10 +941,6 @@ int tg_change_basis_i8(const int8_t* state_in, const int32_t* basis, int8_t* sta
   } while (0)
     if (S == 9) TG_CBM(9, 0, 4);
     if (S == 16) TG_CBM(16, 1, 4);
-#ifdef TG_AB_SWITCHES
-    if (getenv("TG_CB_NW") && atoi(getenv("TG_CB_NW")) == 4) TG_CBM(25, 2, 4);
-    if (getenv("TG_CB_NW") && atoi(getenv("TG_CB_NW")) == 16) TG_CBM(25, 2, 16);
-#endif
     TG_CBM(25, 2, 8);
 #undef TG_CBM
   }

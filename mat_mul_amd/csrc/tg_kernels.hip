@@ -2534,8 +2534,8 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       // (nt loads without / with the wait: 256 MiB 85.6 / 92.2 us, 512 MiB 202.0 / 188.3, 1 GiB 402.5 / 394.8, 1.5 GiB
       // 611.3 / 580.2, 2 GiB 814.5 / 793.5).
       const int64_t bytes = B * a.in_stride;
-      const bool nt = (bytes >= (96ll << 20) || TG_SWITCH("TG_S4_NT_LOADS")) && !TG_SWITCH("TG_S4_NO_NT_LOADS");
-      const bool tw = nt && (bytes >= kS4TokenWaitBytes || TG_SWITCH("TG_S4_TOKEN_WAIT")) && !TG_SWITCH("TG_S4_NO_TOKEN_WAIT");
+      const bool nt = (bytes >= (96ll << 20) || TG_SWITCH("TG_S4_NT_LOADS"));
+      const bool tw = nt && (bytes >= kS4TokenWaitBytes || TG_SWITCH("TG_S4_TOKEN_WAIT"));
       // (a batch that sits in the XCDs' L2s anyway -- BASELINE config 2 -- is swept in one direction)
       const S4StepArgs sa{a.in, a.out, a.actions, a.done, a.overflow, a.B, static_cast<uint32_t>(a.in_stride), a.shift,
                           s4_digits_limit(a.shift), bytes > (16ll << 20) ? a.sweep : 0};
@@ -2697,9 +2697,9 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
         return check_launch(fn);
       }
 #endif
-      if ((nt_band || TG_SWITCH("TG_S16_NT_LOADS")) && !TG_SWITCH("TG_S16_NO_NT_LOADS"))  // (A/B switches: tests)
+      if ((nt_band || TG_SWITCH("TG_S16_NT_LOADS")))  // (A/B switches: tests)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true, true>), dim3((unsigned)blocks), dim3(kBlock), s16_lds_pad, st, a);
-      else if ((B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES")) && !TG_SWITCH("TG_S16_NO_LINES"))  // (A/B switch: tests at small batches)
+      else if ((B * a.in_stride >= (96ll << 20) || TG_SWITCH("TG_S16_LINES")))  // (A/B switch: tests at small batches)
         hipLaunchKernelGGL((s16_step_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kBlock), s16_lds_pad, st, a);
       else
         hipLaunchKernelGGL((s16_step_kernel<MODE, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
@@ -2741,13 +2741,10 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
       // 2 GiB of states, dynamic LDS 0 / 12 / 20 / 24 / 32 / 40 KB (7 / 6 / 5 / 4 / 3 / 3 per CU): 614 / 617 / 597 / 588 / 574 /
       // 572 us; two per CU: 751.  (BASELINE config 5's share, 61 MB: 15.0 / 15.1 / - / 16.1 / 16.1 -- there occupancy wins.)
       int s25_lds_pad = bytes25 >= kNtLoadsToBytes ? 36000 : 0;
-#ifdef TG_AB_SWITCHES
-      if (getenv("TG_S25_LDS_PAD")) s25_lds_pad = atoi(getenv("TG_S25_LDS_PAD"));  // (round 4: the occupancy study of the 2 GiB stream)
-#endif
       const bool nt_band = bytes25 >= kNtLoadsFromBytes && bytes25 < kNtLoadsToBytes;
-      if ((nt_band || TG_SWITCH("TG_S25_NT_LOADS")) && !TG_SWITCH("TG_S25_NO_NT_LOADS"))
+      if ((nt_band || TG_SWITCH("TG_S25_NT_LOADS")))
         hipLaunchKernelGGL((s25_step_kernel<true, true>), dim3((unsigned)B), dim3(kBlock), s25_lds_pad, st, a);
-      else if (((bytes25 >= (96ll << 20) && bytes25 < kNtLoadsToBytes) || TG_SWITCH("TG_S25_LINES")) && !TG_SWITCH("TG_S25_NO_LINES"))
+      else if (((bytes25 >= (96ll << 20) && bytes25 < kNtLoadsToBytes) || TG_SWITCH("TG_S25_LINES")))
         hipLaunchKernelGGL((s25_step_kernel<true, false>), dim3((unsigned)B), dim3(kBlock), s25_lds_pad, st, a);
       else
         hipLaunchKernelGGL((s25_step_kernel<false, false>), dim3((unsigned)B), dim3(kBlock), s25_lds_pad, st, a);
@@ -2761,7 +2758,7 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
     if constexpr (MODE == EXPAND) {
       // S = 16: children of 128 MiB and more leave by non-temporal stores; with keys asked for (tg_expand_keyed_i8) they
       // are formed in the same launch while a child is in registers
-      const bool keyed = a.keys != nullptr && !TG_SWITCH("TG_EXPAND_KEYS_UNFUSED");
+      const bool keyed = a.keys != nullptr;
       if (a.S == 16 && (a.stream_out || keyed)) {
         const int64_t blocks = (B + PGeo<16, 64>::GPB - 1) / PGeo<16, 64>::GPB;
         if (blocks > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
@@ -2857,7 +2854,7 @@ int tg_internal_gen_fused(int8_t* target, int8_t* actions, uint8_t* overflow, co
   // int8 (the reference's {-1,0,1} up to R = 127) and the tiles need no range tracking
   int fmax = 0;
   for (int t = 0; t < D.nv; ++t) fmax = D.val[t] > fmax ? D.val[t] : (-D.val[t] > fmax ? -D.val[t] : fmax);
-  const bool in_range = !basis && static_cast<int64_t>(R) * fmax * fmax * fmax <= 127 && !TG_SWITCH("TG_GF_ALWAYS_CHECK");
+  const bool in_range = !basis && static_cast<int64_t>(R) * fmax * fmax * fmax <= 127;
   const bool lut_values = D.nv == 3 && D.val[0] == -1 && D.val[1] == 0 && D.val[2] == 1 && !TG_SWITCH("TG_GF_NO_LUT");
   if (S == 9) TG_GF(9);
   if (S == 16) TG_GF(16);
@@ -3181,7 +3178,7 @@ int tg_step_emit(int8_t* ring, const int8_t* actions, void* out, float* scalars,
   // S = 16 while the output stays in the caches: one launch (s16_step_emit_kernel)
   const int64_t out_bytes16 = B * T * 4096 * (out_dtype ? 2 : 4);
   const bool fused16 = S == 16 && aligned16(ring) && frame_stride_bytes % 16 == 0 && game_stride_bytes % 16 == 0 && aligned16(actions) &&
-                       (out_bytes16 < tg::kStreamOutBytes || TG_SWITCH("TG_STEP_EMIT_FUSED")) && !TG_SWITCH("TG_STEP_EMIT_UNFUSED");
+                       (out_bytes16 < tg::kStreamOutBytes || TG_SWITCH("TG_STEP_EMIT_FUSED"));
   if (fused16) {
     tg::StepEmitArgs a{ring, actions, out, scalars, done, overflow, B, frame_stride_bytes, game_stride_bytes, T, head_slot, shift, t_step};
     const int64_t blocks = (B + 3) / 4;

@@ -2,7 +2,7 @@
 """The single-step kernel over batch sizes (bench.py's timing machinery):
     python tools/step_sizes_bench.py [--pad N] [--copy] S B K [S B K ...]
 --pad N: game stride rounded up to N bytes (default 16); --copy: also time tg_copy_i8 on the same footprint.
-A/B switches come from the environment (TG_LIB_VARIANT=ab TG_S16_NO_NT_LOADS=1 ...), one process per variant."""
+A/B switches come from the environment (TG_LIB_VARIANT=ab TG_S16_LINES=1 ...), one process per variant."""
 import os
 import sys
 from pathlib import Path
