@@ -997,7 +997,7 @@ def fused_lines(dev, batches=(65536, 1 << 20)):
     from mat_mul_amd import ops
 
     also = []
-    for s2, b2, k2, reps in ((16, 8192, 8, 5),):
+    for s2, b2, k2, reps in ((16, 8192, 8, 5), (25, 4096, 8, 5)):
         tok, tgt = ops.gen_demos(b2, s2, k2, dev, seed=6)
         kids = ops.alloc_states(b2 * k2, s2, dev).unflatten(0, (b2, k2))
         kd = torch.zeros((b2, k2), dtype=torch.uint8, device=dev)

@@ -141,7 +141,7 @@ int tg_expand_i8(const int8_t* state_in, int8_t* state_out, const int8_t* action
 
 /* tg_expand_i8 that also returns keys_out[b*k+i] (uint64 (B,k), 8-byte aligned; NULL = tg_expand_i8) = the
  * tg_hash_u64 key of child (b,i): what extend_tree computes per child with state_to_str (act.py:188-190) before it
- * tests the tree (tg_seen_u64).  At S = 4 and S = 16 (aligned layouts) the key is formed while the child is in registers;
+ * tests the tree (tg_seen_u64).  At S = 4, 16 and 25 (aligned layouts) the key is formed while the child is in registers;
  * other sizes and layouts run the key kernel over the children inside the same call. */
 int tg_expand_keyed_i8(const int8_t* state_in, int8_t* state_out, const int8_t* actions, uint8_t* done,
                        uint8_t* changed, uint8_t* overflow, uint64_t* keys_out, int64_t B, int S, int k,

@@ -2775,6 +2775,17 @@ int launch_apply(const char* fn, const tg::ApplyArgs& a_in, hipStream_t st, bool
         return check_launch(fn);
       }
     }
+    if constexpr (MODE == EXPAND) {
+      if (a.S == 25 && a.keys != nullptr) {  // tg_expand_keyed_i8 at S = 25: the keys from the same launch (a workgroup per parent)
+        if (B > 0x7fffffffLL) return fail(TG_ERR_INVALID, "%s: B too large", fn);
+        const int at = a.nact < PGeo<25, 256>::ATILE ? a.nact : PGeo<25, 256>::ATILE;
+        const int ldsb = packed_lds_bytes<25, 256, MODE, true>(at);
+        (void)hipGetLastError();
+        hipLaunchKernelGGL((packed_kernel<25, 256, MODE, false, true>), dim3((unsigned)B), dim3(kBlock), ldsb, st, a, flim, at);
+        if (keys_fused) *keys_fused = true;
+        return check_launch(fn);
+      }
+    }
     if (a.S == 16) TG_PACKED(16, 64);
     if (a.S == 25) TG_PACKED(25, 256);
   }

@@ -188,31 +188,38 @@ __device__ __forceinline__ uint4 pack_pairs(const uint32_t (&A)[8], uint32_t& nz
 }
 
 // Dynamic LDS (bytes) for `at` staged actions per tile: int16 tables, raw token bytes, flags.
-template <int S, int TS, int MODE>
+// KEYS with a workgroup per parent (TS = 256): + one 64-bit partial key sum per child of the tile and wavefront.
+template <int S, int TS, int MODE, bool KEYS = false>
 constexpr int packed_lds_bytes(int at) {
   using G = PGeo<S, TS>;
   const int tables = G::GPB * at * G::FSTRIDE * 2;
   const int raw = G::GPB * ((at * 3 * S + 8 + 3) & ~3);
   const int nflag = MODE == MANY ? TG_MAX_ACTIONS + 16 : cmax(4, 3 * G::GPB * at);  // MANY: + recompute byte per team
-  return ((tables + raw + ((nflag + 3) & ~3) + 15) & ~15) + 32;  // + two 16-byte slot arrays of block_or2
+  const int keysum = (KEYS && TS == kBlock) ? at * 32 : 0;
+  return ((tables + raw + ((nflag + 3) & ~3) + 15) & ~15) + keysum + 32;  // + two 16-byte slot arrays of block_or2
 }
 
 // NTS (EXPAND at S = 16 only): the children leave by non-temporal stores (268 MB of children: 56.5 -> 50.6 us; the
 // 15 625-byte children of S = 25 end in partial lines and lose with them: 124 -> 134 us).
-// KEYS (round 4; EXPAND at S = 16, tg_expand_keyed_i8): the 64-bit key of every child is formed while the child is in
-// registers -- extend_tree filters every expansion against the tree (act.py:183-195), and a second pass re-reads the
-// 268 MB of children it has just written (8 192 parents x 8).  A team is a wavefront here: the chunk sums meet by shuffles.
+// KEYS (round 4; EXPAND at S = 16 and S = 25, tg_expand_keyed_i8): the 64-bit key of every child is formed while the child is
+// in registers -- extend_tree filters every expansion against the tree (act.py:183-195), and a second pass re-reads the
+// 268 MB (S = 16, 8 192 parents x 8) / 512 MB (S = 25, 4 096 x 8) of children it has just written.  S = 16: a team is a
+// wavefront, the chunk sums meet by shuffles.  S = 25: a team is the workgroup -- every wavefront leaves its partial sum per
+// child in LDS and, behind the barrier the child loop ends with anyway, thread k adds the four of child k.
 template <int S, int TS, int MODE, bool NTS = false, bool KEYS = false>
 __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, int at) {
   using G = PGeo<S, TS>;
-  static_assert(!KEYS || (MODE == EXPAND && TS == 64 && G::TAIL == 0), "keys are formed by the wavefront-per-parent expansion");
+  static_assert(!KEYS || (MODE == EXPAND && (TS == 64 || TS == kBlock)), "keys: a wavefront or a workgroup per parent");
   constexpr bool SUB = (MODE != GENF);  // STEP, MANY, EXPAND subtract
   extern __shared__ __attribute__((aligned(16))) short lds[];
   const int raw_stride = (at * 3 * S + 8 + 3) & ~3;  // bytes of raw tokens per team
   int8_t* const raw_all = reinterpret_cast<int8_t*>(lds + G::GPB * at * G::FSTRIDE);
   uint8_t* const flags = reinterpret_cast<uint8_t*>(raw_all + G::GPB * raw_stride);
   // the last 32 bytes of the dynamic LDS (16-byte aligned): two slot arrays for block_or2
-  uint32_t* const or_slots = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(lds) + packed_lds_bytes<S, TS, MODE>(at) - 32);
+  uint32_t* const or_slots = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(lds) + packed_lds_bytes<S, TS, MODE, KEYS>(at) - 32);
+  // (KEYS, TS = 256) hpart[k * 4 + wave]: the wavefront's share of child k's key sum; in front of the OR slots, 16-byte aligned
+  unsigned long long* const hpart = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(or_slots) - at * 32);
+  (void)hpart;
 
   const int tid = threadIdx.x;
   const int team = tid / TS, lt = tid % TS;
@@ -285,15 +292,22 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
     }
     if constexpr (KEYS) {  // the exact form wrote the children to memory: every team keys those of its parent from there
       __syncthreads();
-      if (live) {
-        for (int k = 0; k < a.nact; ++k) {
-          const int64_t child = g * a.nact + k;
-          uint64_t hk = 0;
+      for (int k = 0; k < a.nact; ++k) {  // (workgroup-uniform trip count: the TS = 256 form has barriers inside)
+        const int64_t child = g * a.nact + k;
+        uint64_t hk = 0;
+        if (live) {
 #pragma unroll
           for (int n = 0; n < G::NCH; ++n)
-            if (cv[n]) hk += hash_chunk(*reinterpret_cast<const uint4*>(a.out + child * a.out_stride + 16 * (lt + G::TSA * n)), lt + G::TSA * n);
-          for (int off = 32; off > 0; off >>= 1) hk += __shfl_xor(hk, off);
-          if (lt == 0) a.keys[child] = hash_finish(hk, S * S * S);
+            if (cv[n]) hk += hash_chunk(load_chunk<G::TAIL>(a.out + child * a.out_stride + 16 * (lt + G::TSA * n), ctail[n]), lt + G::TSA * n);
+        }
+        for (int off = 32; off > 0; off >>= 1) hk += __shfl_xor(hk, off);
+        if constexpr (TS == 64) {
+          if (lt == 0 && live) a.keys[child] = hash_finish(hk, S * S * S);
+        } else {
+          if ((tid & 63) == 0) hpart[tid >> 6] = hk;
+          __syncthreads();
+          if (tid == 0 && live) a.keys[child] = hash_finish(hpart[0] + hpart[1] + hpart[2] + hpart[3], S * S * S);
+          __syncthreads();
         }
       }
     }
@@ -556,7 +570,11 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
         }
         if constexpr (KEYS) {
           for (int off = 32; off > 0; off >>= 1) hk += __shfl_xor(hk, off);
-          if (lt == 0 && live) a.keys[child] = hash_finish(hk, S * S * S);
+          if constexpr (TS == 64) {
+            if (lt == 0 && live) a.keys[child] = hash_finish(hk, S * S * S);
+          } else {
+            if ((tid & 63) == 0) hpart[4 * k + (tid >> 6)] = hk;  // met behind the tile's closing barrier
+          }
         }
         if (nz) nzF[k] = 1;
         if (covf & 0xFF00FF00u) ovF[k] = 1;
@@ -565,6 +583,8 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(ApplyArgs a, int flim, i
       for (int k = lt; k < na; k += TS) {
         if (!live) continue;
         const int64_t child = g * a.nact + a0 + k;
+        if constexpr (KEYS && TS == kBlock)
+          a.keys[child] = hash_finish(hpart[4 * k] + hpart[4 * k + 1] + hpart[4 * k + 2] + hpart[4 * k + 3], S * S * S);
         a.done[child] = nzF[k] ? 0 : 1;
         if (a.changed) a.changed[child] = nnF[k];
         if (a.overflow && ovF[k]) a.overflow[child] = 1;

@@ -96,13 +96,15 @@ def test_seen_full_table_sets_status_and_loses_nothing_silently():
     assert int((fresh == 0).sum()) == 8
 
 
-@pytest.mark.parametrize("B,k", [(1, 1), (5, 8), (131, 3), (37, 70), (2048, 8)])
-def test_expand_keys_fused_at_s16(B, k):
-    """Round 4: at S=16 tg_expand_keyed_i8 forms the keys inside the expansion kernel (packed_kernel<16, 64, EXPAND, *, true>):
-    ragged batches, more actions than one staging tile, null actions, overflowing children, and parents whose factors are
-    beyond the packed form (the workgroup's exact fallback writes the children, then keys them from memory) -- keys ==
-    tg_hash_u64 of the children == the oracle's key, children / done / changed == the oracle."""
-    S = 16
+@pytest.mark.parametrize("S,B,k", [(16, 1, 1), (16, 5, 8), (16, 131, 3), (16, 37, 70), (16, 2048, 8),
+                                   (25, 1, 1), (25, 3, 8), (25, 37, 3), (25, 5, 70), (25, 300, 8)])
+def test_expand_keys_fused_at_s16_and_s25(S, B, k):
+    """Round 4: at S=16 and S=25 tg_expand_keyed_i8 forms the keys inside the expansion kernel (packed_kernel<.., EXPAND, *,
+    true>: a wavefront per parent and shuffles at S=16, a workgroup per parent and per-wavefront partial sums in LDS at
+    S=25, whose last chunk holds nine bytes): ragged batches, more actions than one staging tile, null actions, overflowing
+    children, and parents whose factors are beyond the packed form (the workgroup's exact fallback writes the children,
+    then keys them from memory) -- keys == tg_hash_u64 of the children == the oracle's key, children / done / changed ==
+    the oracle."""
     rng = np.random.default_rng(B * 100 + k)
     st = rng.integers(-2, 3, size=(B, S, S, S)).astype(np.int8)
     ac = rng.choice([0, 1, 2], p=[0.15, 0.7, 0.15], size=(B, k, 3 * S)).astype(np.int8)
