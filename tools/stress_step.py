@@ -103,10 +103,11 @@ for c in range(cases):
         ok = ok and np.array_equal(ch.cpu().numpy(), wc) and np.array_equal(ovk.cpu().numpy(), wo)
         ok = ok and np.array_equal(t.cpu().numpy(), st)
     # round 4: keys formed inside the expansion (S = 4, 16) and step + model input in one kernel (S = 4, 16), same material
-    if S in (4, 16) and abs(shift) <= 127:
+    if S in (4, 16, 25) and abs(shift) <= 127:
         kids, d, ch, keys = ops.expand(padded(st), torch.from_numpy(ak).to(DEV), shift=shift, want_keys=True)
         ok = ok and np.array_equal(kids.cpu().numpy(), wk)
         ok = ok and np.array_equal(keys.cpu().numpy().view(np.uint64), O.state_hash(wk.reshape(B * k, S, S, S)).reshape(B, k))
+    if S in (4, 16) and abs(shift) <= 127:
         T = int(rng.integers(1, 5))
         frames = rng.integers(-3, 4, size=(B, T, S, S, S)).astype(np.int8)
         head = int(rng.integers(T))
