@@ -258,6 +258,20 @@ for bursts in ((1,) * K, (1, 4, 2, 9, 1, 3, 8, 8)):
     side.synchronize()
     assert int(status[0]) == 0
     assert np.array_equal(host(t), cur) and np.array_equal(host(done), want_done) and bool((prog == K).all())
+# never released beyond step 1: every wavefront gives up after its time bound, the state stops where the words stopped
+t = ops.alloc_states(B, S, DEV); t.copy_(dev(st))
+ready = torch.zeros(K, dtype=torch.int32, device=DEV); ready[:2] = 1
+status = torch.zeros(1, dtype=torch.int32, device=DEV)
+prog = torch.zeros(ops.step_stream_layout(B, S, DEV)[0], dtype=torch.int32, device=DEV)
+import time
+t0 = time.perf_counter()
+ops.step_stream(t, dev(ac), ready=ready, progress=prog, status=status)
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+two = st.copy()
+for k in range(2):
+    two, _, _ = O.step_i8(two, ac[k])
+assert int(status[0]) == 1 and np.array_equal(host(t), two) and bool((prog == 2).all()) and 0.9 < el < 3.0, (int(status[0]), el)
 print("LANES_OK")
 '''
 
