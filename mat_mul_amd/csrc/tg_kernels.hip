@@ -998,6 +998,34 @@ struct StreamArgs {
   uint32_t wait_ticks;  // how long a wavefront waits for a ready word: ticks of s_memrealtime (100 MHz)
 };
 
+// The ready-word protocol shared by the four resident steppers (D = steps a wavefront takes at once, <= 8).
+// stream_released: how many of ready[kp], ready[kp + 1], ... are set without a gap, given lane's word in v (lanes < D,
+// kp + lane < K); wave-uniform, <= D.
+template <int D>
+__device__ __forceinline__ int stream_released(const StreamArgs& a, uint32_t v, int kp, int lane) {
+  const unsigned long long m = __ballot(lane < D && kp + lane < a.K && v != 0);
+  return static_cast<int>(__builtin_ctzll(~m));
+}
+// stream_wait_released: poll until step kp is released (relaxed agent-scope loads: they bypass this CU's L1).  Bounded in
+// TIME: the first miss starts a clock on s_memrealtime (100 MHz, one counter for the whole chip), after a.wait_ticks the
+// wavefront sets *status and the caller leaves (returns 0).
+template <int D>
+__device__ __forceinline__ int stream_wait_released(const StreamArgs& a, int kp, int lane) {
+  uint64_t t0 = 0;
+  for (;;) {
+    const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const int n = stream_released<D>(a, v, kp, lane);
+    if (n) return n;
+    const uint64_t now = __builtin_amdgcn_s_memrealtime();
+    if (t0 == 0) t0 = now;
+    if (now - t0 >= a.wait_ticks) {
+      if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return 0;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
 template <int NG>
 __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
   const int lane = threadIdx.x & 63, q = lane & 3, lg = lane >> 2;
@@ -1072,28 +1100,8 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel(StreamArgs a) {
     asm volatile("" : "+v"(pollv));
   };
   // how many of ready[kp], ready[kp + 1], ... are set without a gap, given lane's word in v (lanes < D, kp + lane < K)
-  auto released = [&](uint32_t v, int kp) {
-    const unsigned long long m = __ballot(lane < D && kp + lane < a.K && v != 0);
-    return static_cast<int>(__builtin_ctzll(~m));  // uniform, <= D
-  };
-  auto poll_now = [&](int kp) {  // relaxed agent-scope loads (bypass this CU's L1)
-    const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    return released(v, kp);
-  };
-  auto wait_released = [&](int kp) {  // bounded in TIME (a.wait_ticks); 0 = gave up
-    uint64_t t0 = 0;  // the first miss starts the clock: s_memrealtime, 100 MHz, the same counter on every XCD
-    for (;;) {
-      const int n = poll_now(kp);
-      if (n) return n;
-      const uint64_t now = __builtin_amdgcn_s_memrealtime();
-      if (t0 == 0) t0 = now;
-      if (now - t0 >= a.wait_ticks) {
-        if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  };
+  auto released = [&](uint32_t v, int kp) { return stream_released<D>(a, v, kp, lane); };
+  auto wait_released = [&](int kp) { return stream_wait_released<D>(a, kp, lane); };
   // (the state is in its registers before the first asm load: hipcc waits for its own loads with vmcnt(0) wherever it
   // thinks one may still be pending -- inside the loop that would be every block)
 #pragma unroll
@@ -1275,25 +1283,8 @@ __global__ __launch_bounds__(kBlock) void s4_stream_kernel_lanes(StreamArgs a) {
     for (int d = 0; d < D; ++d) asm volatile("" : "+v"(tk[d]));
     asm volatile("" : "+v"(pollv));
   };
-  auto released = [&](uint32_t v, int kp) {
-    const unsigned long long m = __ballot(lane < D && kp + lane < a.K && v != 0);
-    return static_cast<int>(__builtin_ctzll(~m));  // uniform, <= D
-  };
-  auto wait_released = [&](int kp) {  // bounded in TIME (a.wait_ticks); 0 = gave up
-    uint64_t t0 = 0;
-    for (;;) {
-      const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      const int n = released(v, kp);
-      if (n) return n;
-      const uint64_t now = __builtin_amdgcn_s_memrealtime();
-      if (t0 == 0) t0 = now;
-      if (now - t0 >= a.wait_ticks) {
-        if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  };
+  auto released = [&](uint32_t v, int kp) { return stream_released<D>(a, v, kp, lane); };
+  auto wait_released = [&](int kp) { return stream_wait_released<D>(a, kp, lane); };
   auto publish = [&](int k) {
     if (lane == 0) __hip_atomic_store(a.progress + unit, static_cast<uint32_t>(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
@@ -1874,25 +1865,8 @@ __global__ __launch_bounds__(kBlock, 8) void s16_stream_kernel(StreamArgs a) {
     }
     __builtin_amdgcn_wave_barrier();  // (LDS serves one wavefront's accesses in order)
   };
-  auto released = [&](uint32_t v, int kp) {  // how many of ready[kp], ready[kp + 1], ... are set without a gap (<= D)
-    const unsigned long long m = __ballot(lane < D && kp + lane < a.K && v != 0);
-    return static_cast<int>(__builtin_ctzll(~m));
-  };
-  auto wait_released = [&](int kp) {  // bounded in TIME (a.wait_ticks); 0 = gave up
-    uint64_t t0 = 0;  // the first miss starts the clock: s_memrealtime, 100 MHz, the same counter on every XCD
-    for (;;) {
-      const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      const int n = released(v, kp);
-      if (n) return n;
-      const uint64_t now = __builtin_amdgcn_s_memrealtime();
-      if (t0 == 0) t0 = now;
-      if (now - t0 >= a.wait_ticks) {
-        if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  };
+  auto released = [&](uint32_t v, int kp) { return stream_released<D>(a, v, kp, lane); };
+  auto wait_released = [&](int kp) { return stream_wait_released<D>(a, kp, lane); };
   // (the state is in its registers before the first asm load, or hipcc waits for it -- with vmcnt(0) -- inside the loop)
 #pragma unroll
   for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(x[n].x), "+v"(x[n].y), "+v"(x[n].z), "+v"(x[n].w));
@@ -2083,25 +2057,8 @@ __global__ __launch_bounds__(kBlock, 4) void s25_stream_kernel(StreamArgs a) {
     }
   };
   auto arrived = [&]() { __builtin_amdgcn_wave_barrier(); };  // behind the counted wait: the rows are in LDS
-  auto released = [&](uint32_t v, int kp) {
-    const unsigned long long m = __ballot(lane < D && kp + lane < a.K && v != 0);
-    return static_cast<int>(__builtin_ctzll(~m));
-  };
-  auto wait_released = [&](int kp) {  // bounded in TIME (a.wait_ticks); 0 = gave up
-    uint64_t t0 = 0;  // the first miss starts the clock: s_memrealtime, 100 MHz, the same counter on every XCD
-    for (;;) {
-      const uint32_t v = (lane < D && kp + lane < a.K) ? __hip_atomic_load(a.ready + kp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      const int n = released(v, kp);
-      if (n) return n;
-      const uint64_t now = __builtin_amdgcn_s_memrealtime();
-      if (t0 == 0) t0 = now;
-      if (now - t0 >= a.wait_ticks) {
-        if (lane == 0 && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  };
+  auto released = [&](uint32_t v, int kp) { return stream_released<D>(a, v, kp, lane); };
+  auto wait_released = [&](int kp) { return stream_wait_released<D>(a, kp, lane); };
   // (the state is in its registers before the first asm load, or hipcc waits for it -- with vmcnt(0) -- inside the loop)
 #pragma unroll
   for (int n = 0; n < NSLOT; ++n) asm volatile("" : "+v"(x[n].x), "+v"(x[n].y), "+v"(x[n].z), "+v"(x[n].w));
